@@ -1,0 +1,648 @@
+// Per-block ("lane") logic of the denoise -> tokenise -> chunk path.
+//
+// The packed corpus is cut into 64-byte blocks; one GPU lane owns one block and represents
+// every per-byte property as a 64-bit mask (bit j = byte j of the block).  A wavefront
+// therefore covers 4 KiB and a 256-thread workgroup a 16 KiB tile.  Everything that crosses a
+// block boundary travels as a small associative summary (monoid) that is combined by
+// wave/workgroup scans on the device and by a plain sequential fold in the host simulator
+// (trp_sim.cpp), which runs exactly these functions so the algorithm can be checked against the
+// CPU oracle without a GPU.
+//
+// Reference semantics restated here (paths relative to the reference checkout):
+//   src/preprocessor/backends/denoiser_preprocessor.rs:21-268  (gates 1-3, table stripping)
+//   src/tokenizer.rs:55-65                                      (split_whitespace)
+//   src/chunking/sliding_window.rs:40-115                       (window arithmetic)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TRP_HD __host__ __device__ inline
+#else
+#define TRP_HD inline
+#endif
+
+namespace trp {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+constexpr int BLOCK = 64;          // bytes per lane
+constexpr int TILE_BLOCKS = 256;   // lanes per workgroup
+constexpr int TILE = BLOCK * TILE_BLOCKS;
+constexpr int HALO = 16;           // staged bytes before and after a tile (UTF-8 look-around)
+constexpr int MAX_OVERLAPS = 16;
+
+// ---- character classes (bits of the per-byte class code) -------------------------------------
+enum : u32 { C_WS = 1, C_NL = 2, C_CR = 4, C_PIPE = 8, C_DIGIT = 16, C_ALPHA = 32, C_HIGH = 64 };
+
+// Class code of an ASCII byte; bytes >= 0x80 only get C_HIGH (resolved by decoding).
+TRP_HD u32 ascii_class(u32 b) {
+    u32 c = 0;
+    if (b >= 0x80) return C_HIGH;
+    if (b == 0x20 || (b - 9u) < 5u) c |= C_WS;
+    if (b == 0x0A) c |= C_NL;
+    if (b == 0x0D) c |= C_CR;
+    if (b == 0x7C) c |= C_PIPE;
+    if ((b - 0x30u) < 10u) c |= C_DIGIT;
+    if (((b | 0x20u) - 0x61u) < 26u) c |= C_ALPHA;
+    return c;
+}
+
+// Unicode White_Space beyond ASCII (char::is_whitespace).
+TRP_HD bool cp_is_ws_high(u32 cp) {
+    return cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) ||
+           cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+
+// Unicode Alphabetic (char::is_alphabetic) through the generated two-stage table.
+TRP_HD bool cp_is_alpha_high(u32 cp, const u8* stage1, const u32* stage2, u32 stage1_len) {
+    u32 blk = cp >> 8;
+    if (blk >= stage1_len) return false;
+    u32 row = stage1[blk];
+    u32 o = cp & 255u;
+    return (stage2[row * 8 + (o >> 5)] >> (o & 31u)) & 1u;
+}
+
+struct UniTables {
+    const u8* stage1;
+    const u32* stage2;
+    u32 stage1_len;
+};
+
+// Decode the multi-byte sequence whose lead byte is at q[0] (q[0] >= 0xC0).  q[1..3] must be
+// readable.  Returns the sequence length (2..4) and the scalar value, or 0 when malformed.
+TRP_HD int decode_lead(const u8* q, u32* cp) {
+    u32 b0 = q[0];
+    int n;
+    u32 v;
+    if (b0 < 0xE0) { n = 2; v = b0 & 0x1F; }
+    else if (b0 < 0xF0) { n = 3; v = b0 & 0x0F; }
+    else { n = 4; v = b0 & 0x07; }
+    for (int i = 1; i < n; i++) {
+        u32 c = q[i];
+        if ((c & 0xC0) != 0x80) return 0;
+        v = (v << 6) | (c & 0x3F);
+    }
+    *cp = v;
+    return n;
+}
+
+// ---- bit helpers ---------------------------------------------------------------------------------
+TRP_HD int popc(u64 x) { return __builtin_popcountll(x); }
+TRP_HD int ctz(u64 x) { return __builtin_ctzll(x); }          // x != 0
+TRP_HD int top(u64 x) { return 63 - __builtin_clzll(x); }     // x != 0: index of highest set bit
+TRP_HD u64 below(int j) { return j >= 64 ? ~0ull : ((1ull << j) - 1ull); }   // bits < j
+TRP_HD u64 bit(int j) { return 1ull << j; }
+TRP_HD u64 brev(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#elif defined(__has_builtin) && __has_builtin(__builtin_bitreverse64)
+    return __builtin_bitreverse64(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+
+// ---- per-block class masks -----------------------------------------------------------------------
+struct Cls {
+    u64 ws, nl, cr, pipe, dig, alp;
+};
+
+// Classify `nvalid` bytes starting at blk[0].  blk[-4..-1] and blk[64..67] must be readable
+// (staged halo; zero where the corpus has no byte).  `ws` covers every byte of a whitespace
+// character; `alp` is set on the lead byte of an alphabetic character only.
+TRP_HD Cls classify_block(const u8* blk, int nvalid, const UniTables& ut) {
+    Cls c = {0, 0, 0, 0, 0, 0};
+    u64 high = 0;
+    for (int j = 0; j < nvalid; j++) {
+        u32 k = ascii_class(blk[j]);
+        u64 b = 1ull << j;
+        if (k & C_WS) c.ws |= b;
+        if (k & C_NL) c.nl |= b;
+        if (k & C_CR) c.cr |= b;
+        if (k & C_PIPE) c.pipe |= b;
+        if (k & C_DIGIT) c.dig |= b;
+        if (k & C_ALPHA) c.alp |= b;
+        if (k & C_HIGH) high |= b;
+    }
+    while (high) {
+        int j = ctz(high);
+        high &= high - 1;
+        u32 b0 = blk[j];
+        u32 cp;
+        if (b0 >= 0xC0) {
+            if (decode_lead(blk + j, &cp)) {
+                if (cp_is_ws_high(cp)) c.ws |= bit(j);
+                else if (cp_is_alpha_high(cp, ut.stage1, ut.stage2, ut.stage1_len)) c.alp |= bit(j);
+            }
+        } else {
+            // continuation byte: it is whitespace iff its character is
+            for (int k = 1; k <= 3; k++) {
+                u32 l = blk[j - k];
+                if (l >= 0xC0) {
+                    int n = decode_lead(blk + j - k, &cp);
+                    if (n > k && cp_is_ws_high(cp)) c.ws |= bit(j);
+                    break;
+                }
+                if (l < 0x80) break;
+            }
+        }
+    }
+    return c;
+}
+
+// ---- line structure ------------------------------------------------------------------------------
+struct Derived {
+    u64 V;     // bytes that exist (below the end of the corpus)
+    u64 RS;    // first byte of a record
+    u64 LS;    // first byte of a line (record start, or the byte after a terminator)
+    u64 TERM;  // line terminators after normalisation: '\n', and '\r' not followed by '\n'
+    u64 DEL;   // '\r' of a "\r\n" pair (removed by the normalisation)
+    u64 LC;    // line content: V minus TERM and DEL
+};
+
+// next_nl_same_rec: the byte after the block exists, is '\n' and is not a record start.
+// prev_term: the byte before the block exists and is a line terminator.
+TRP_HD Derived derive(const Cls& c, u64 V, u64 RS, bool next_nl_same_rec, bool prev_term) {
+    Derived d;
+    d.V = V;
+    d.RS = RS & V;
+    d.DEL = c.cr & (((c.nl & ~RS) >> 1) | (next_nl_same_rec ? bit(63) : 0)) & V;
+    d.TERM = (c.nl | (c.cr & ~d.DEL)) & V;
+    d.LS = (d.RS | (d.TERM << 1) | (prev_term ? 1ull : 0ull)) & V;
+    d.LC = V & ~(d.TERM | d.DEL);
+    return d;
+}
+
+// Is the byte before the block a terminator?  prev = that byte, cur0 = first byte of the block,
+// rs0 = first byte of the block starts a record.
+TRP_HD bool prev_is_term(bool has_prev, u32 prev, bool has_cur, u32 cur0, bool rs0) {
+    if (!has_prev) return false;
+    if (prev == 0x0A) return true;
+    if (prev == 0x0D) return !(has_cur && cur0 == 0x0A && !rs0);
+    return false;
+}
+
+// Statistics of (a part of) one line.  f: [1:0] class of first non-whitespace content byte
+// (0 none, 1 pipe, 2 text), [3:2] class of the last one, [4] a text byte was seen.
+struct LineSum {
+    u32 d, a, p, f;
+};
+TRP_HD LineSum ls_empty() { LineSum s = {0, 0, 0, 0}; return s; }
+TRP_HD u32 ls_first(const LineSum& s) { return s.f & 3u; }
+TRP_HD u32 ls_last(const LineSum& s) { return (s.f >> 2) & 3u; }
+TRP_HD bool ls_seen_text(const LineSum& s) { return (s.f >> 4) & 1u; }
+// A = earlier part, B = later part of the same line.
+TRP_HD LineSum ls_add(const LineSum& A, const LineSum& B) {
+    LineSum s;
+    s.d = A.d + B.d;
+    s.a = A.a + B.a;
+    s.p = A.p + B.p;
+    u32 first = ls_first(A) ? ls_first(A) : ls_first(B);
+    u32 last = ls_last(B) ? ls_last(B) : ls_last(A);
+    s.f = first | (last << 2) | ((A.f | B.f) & 16u);
+    return s;
+}
+TRP_HD LineSum range_sum(const Cls& c, const Derived& d, u64 R) {
+    LineSum s;
+    u64 lc = d.LC & R;
+    s.d = popc(c.dig & lc);
+    s.a = popc(c.alp & lc);
+    s.p = popc(c.pipe & lc);
+    u64 nw = lc & ~c.ws;
+    u32 f = 0;
+    if (nw) {
+        u32 first = (c.pipe >> ctz(nw)) & 1u ? 1u : 2u;
+        u32 last = (c.pipe >> top(nw)) & 1u ? 1u : 2u;
+        f = first | (last << 2);
+        if (nw & ~c.pipe) f |= 16u;
+    }
+    s.f = f;
+    return s;
+}
+
+// Forward summary of a run of blocks.  g: bit0 has_ls, bit1 has_rs, bit2 alpha before the first
+// record start (or anywhere when there is none), bit3 alpha at/after the last record start,
+// bit4/bit5: "the record has an alphabetic char before the last line start" = c0 | (c1 & AR_in)
+// where AR_in is the same statement about the bytes before the run.
+struct J {
+    LineSum head;   // bytes before the first line start (whole run when has_ls == 0)
+    LineSum tail;   // bytes from the last line start on (valid when has_ls)
+    u32 g;
+};
+enum : u32 { G_LS = 1, G_RS = 2, G_AH = 4, G_AT = 8, G_C0 = 16, G_C1 = 32 };
+TRP_HD J j_identity() { J j; j.head = ls_empty(); j.tail = ls_empty(); j.g = 0; return j; }
+
+TRP_HD J j_combine(const J& A, const J& B) {
+    J C;
+    bool als = A.g & G_LS, bls = B.g & G_LS;
+    if (!als && !bls) { C.head = ls_add(A.head, B.head); C.tail = ls_empty(); }
+    else if (als && !bls) { C.head = A.head; C.tail = ls_add(A.tail, B.head); }
+    else if (!als && bls) { C.head = ls_add(A.head, B.head); C.tail = B.tail; }
+    else { C.head = A.head; C.tail = B.tail; }
+    u32 g = (A.g | B.g) & (G_LS | G_RS);
+    bool ars = A.g & G_RS, brs = B.g & G_RS;
+    bool ah = ars ? (A.g & G_AH) != 0 : ((A.g | B.g) & G_AH) != 0;
+    bool at = brs ? (B.g & G_AT) != 0 : ((A.g | B.g) & G_AT) != 0;
+    if (ah) g |= G_AH;
+    if (at) g |= G_AT;
+    if (bls) {
+        bool known = ars ? (A.g & G_AT) != 0 : (A.g & G_AH) != 0;
+        bool dep = !ars;
+        if ((B.g & G_C0) || ((B.g & G_C1) && known)) g |= G_C0;
+        if ((B.g & G_C1) && dep) g |= G_C1;
+    } else {
+        g |= A.g & (G_C0 | G_C1);
+    }
+    C.g = g;
+    return C;
+}
+
+TRP_HD J lane_J(const Cls& c, const Derived& d) {
+    J j;
+    u32 g = 0;
+    if (d.LS == 0) {
+        j.head = range_sum(c, d, d.V);
+        j.tail = ls_empty();
+    } else {
+        int first = ctz(d.LS), last = top(d.LS);
+        j.head = range_sum(c, d, below(first));
+        j.tail = range_sum(c, d, ~below(last));
+        g |= G_LS;
+        u64 rsb = d.RS & below(last + 1);
+        if (rsb) {
+            if (c.alp & below(last) & ~below(top(rsb))) g |= G_C0;
+        } else {
+            if (c.alp & below(last)) g |= G_C0;
+            g |= G_C1;
+        }
+    }
+    u64 alp = c.alp & d.V;
+    if (d.RS == 0) {
+        if (alp) g |= G_AH | G_AT;
+    } else {
+        g |= G_RS;
+        if (alp & below(ctz(d.RS))) g |= G_AH;
+        if (alp & ~below(top(d.RS))) g |= G_AT;
+    }
+    j.g = g;
+    return j;
+}
+
+// Backward summary: the bytes of a run that belong to the line entering it from the left.
+struct S {
+    LineSum head;
+    u32 has_ls;
+};
+TRP_HD S s_identity() { S s; s.head = ls_empty(); s.has_ls = 0; return s; }
+// A = earlier run, B = later run.
+TRP_HD S s_combine(const S& A, const S& B) {
+    S c;
+    c.has_ls = A.has_ls | B.has_ls;
+    c.head = A.has_ls ? A.head : ls_add(A.head, B.head);
+    return c;
+}
+TRP_HD S s_from_J(const J& j) { S s; s.head = j.head; s.has_ls = j.g & G_LS; return s; }
+
+// ---- configuration ---------------------------------------------------------------------------------
+struct DevCfg {
+    u32 denoise_enabled;
+    u32 strip_markdown;
+    float max_digit_ratio;
+    u32 max_window_tokens;
+    u32 n_overlaps;
+    u32 summary_fallback_tokens;
+    u32 overlaps[MAX_OVERLAPS];
+};
+
+// digits as f32 / (digits + alpha) as f32 > max   (denoiser_preprocessor.rs:37-45, :115-121)
+TRP_HD bool ratio_exceeds(u32 d, u32 a, float max_ratio) {
+    u32 t = d + a;
+    if (t == 0) return 0.0f > max_ratio;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __fdiv_rn((float)d, (float)t);
+#else
+    volatile float fd = (float)d, ft = (float)t;
+    volatile float r = fd / ft;
+#endif
+    return r > max_ratio;
+}
+TRP_HD bool ratio_exceeds64(u64 d, u64 a, float max_ratio) {
+    u64 t = d + a;
+    if (t == 0) return 0.0f > max_ratio;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __fdiv_rn((float)d, (float)t);
+#else
+    volatile float fd = (float)d, ft = (float)t;
+    volatile float r = fd / ft;
+#endif
+    return r > max_ratio;
+}
+
+// ---- the emit plan -----------------------------------------------------------------------------------
+// Four bit planes per block.  C: the byte is copied.  TOK: the byte belongs to a token of the output
+// (copied and not whitespace).  PSP / PNL: one ' ' / '\n' is emitted in front of the (copied) byte.
+// A set TOK bit on a byte that is not copied marks the first byte of a digit-heavy ("gate 3") line
+// that is still to be solved; there PSP means "table line" and PNL "the record already has a kept
+// line before this one".
+struct Plan {
+    u64 C, TOK, PSP, PNL;
+};
+
+struct LaneCarry {
+    LineSum ci;     // the current line, from its start to the start of this block
+    bool ci_rab;    // the record has an alphabetic char before that line's start
+    bool ar_in;     // the record has an alphabetic char before this block
+    LineSum co;     // the rest of the block's last line after the end of this block
+    bool next_rs;   // the byte after this block starts a record (or does not exist)
+};
+
+TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
+    LaneCarry k;
+    k.ci = (P.g & G_LS) ? P.tail : P.head;
+    k.ci_rab = (P.g & G_C0) != 0;
+    k.ar_in = (P.g & G_RS) ? (P.g & G_AT) != 0 : (P.g & G_AH) != 0;
+    k.co = X.head;
+    k.next_rs = next_rs;
+    return k;
+}
+
+TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg) {
+    Plan out = {0, 0, 0, 0};
+    const u64 T = d.LC & ~c.ws & ~c.pipe;   // text bytes
+    const u64 W = d.LC & c.ws;              // whitespace inside lines
+    const bool head0 = !(d.LS & 1ull);      // the block starts inside a line begun earlier
+    // Cell trimming of table rows (strip_table_pipes): a whitespace byte survives only when the
+    // nearest non-whitespace byte on either side, within the line, is text (not a pipe).
+    const u64 cin_text = (head0 && ls_last(k.ci) == 2u) ? 1ull : 0ull;
+    const u64 Wp = W & ~d.LS;
+    const u64 SL = ((T << 1) | cin_text) & Wp;
+    const u64 LT = Wp & ~(Wp + SL);
+    const u64 Wq = W & ~((d.LS >> 1) | (k.next_rs ? bit(63) : 0ull));
+    const u64 cin_right = (ls_first(k.co) == 2u) ? bit(63) : 0ull;
+    const u64 SR = ((T >> 1) | cin_right) & Wq;
+    const u64 rW = brev(Wq), rS = brev(SR);
+    const u64 RT = brev(rW & ~(rW + rS));
+    const u64 IW = LT & RT;
+    const u64 prevtext = (((T | LT) << 1) | cin_text) & ~d.LS;
+    const u64 CS = T & ~prevtext;   // first byte of a trimmed cell
+
+    int s = 0;
+    bool is_head = head0;
+    for (;;) {
+        u64 nxt = d.LS & ~below(s + 1);
+        int e = nxt ? ctz(nxt) : 64;
+        u64 R = below(e) & ~below(s) & d.V;
+        if (R) {
+            LineSum tot = range_sum(c, d, R);
+            if (is_head) tot = ls_add(k.ci, tot);
+            if (!nxt) tot = ls_add(tot, k.co);
+            if (tot.a > 0) {
+                bool rab;
+                if (is_head) rab = k.ci_rab;
+                else {
+                    u64 rsb = d.RS & below(s + 1);
+                    if (rsb) rab = (c.alp & below(s) & ~below(top(rsb))) != 0;
+                    else rab = k.ar_in || (c.alp & below(s)) != 0;
+                }
+                bool table = cfg.strip_markdown && ls_first(tot) == 1u && tot.p >= 2u;
+                bool g3 = ratio_exceeds(tot.d, tot.a, cfg.max_digit_ratio);
+                if (g3) {
+                    if (!is_head) {
+                        out.TOK |= bit(s);
+                        if (table) out.PSP |= bit(s);
+                        if (rab) out.PNL |= bit(s);
+                    }
+                } else if (!table) {
+                    out.C |= d.LC & R;
+                    out.TOK |= d.LC & R & ~c.ws;
+                    if (!is_head && rab) out.PNL |= bit(s);
+                } else {
+                    out.C |= R & (T | IW);
+                    out.TOK |= R & T;
+                    u64 cs = CS & R, Tr = T & R;
+                    if (Tr) {
+                        u64 first = Tr & (~Tr + 1ull);
+                        if (is_head && ls_seen_text(k.ci)) out.PSP |= cs;
+                        else {
+                            out.PSP |= cs & ~first;
+                            if (rab && (cs & first)) out.PNL |= first;
+                        }
+                    }
+                }
+            }
+        }
+        if (!nxt) break;
+        s = e;
+        is_head = false;
+    }
+    return out;
+}
+
+// Plan of the pass-through configuration (denoiser disabled): every byte is "copied" in place and
+// tokens are the runs of non-whitespace bytes.
+TRP_HD Plan plan_passthrough(const Cls& c, u64 V) {
+    Plan p;
+    p.C = V;
+    p.TOK = V & ~c.ws;
+    p.PSP = 0;
+    p.PNL = 0;
+    return p;
+}
+
+// Token starts / ends of a block from its plan.  prev_tok: the byte before the block is a token
+// byte; next_tok: the byte after it is; next_rs: the byte after the block starts a record.
+TRP_HD u64 token_starts(u64 TOKC, u64 RS, bool prev_tok) {
+    return TOKC & (~((TOKC << 1) | (prev_tok ? 1ull : 0ull)) | RS);
+}
+TRP_HD u64 token_ends(u64 TOKC, u64 RS, bool next_tok, bool next_rs) {
+    u64 nt = (TOKC >> 1) | (next_tok ? bit(63) : 0ull);
+    u64 nr = (RS >> 1) | (next_rs ? bit(63) : 0ull);
+    return TOKC & (~nt | nr);
+}
+
+// ---- chunk windows (sliding_window.rs:40-115) --------------------------------------------------------
+struct ChunkDesc {
+    u32 record, kind, index, overlap, span, tok_begin, tok_end, reserved;
+};
+
+TRP_HD u64 chunk_windows(u64 T, u64 span, u64 overlap) {
+    if (span == 0) return T;
+    u64 stride = span > overlap ? span - overlap : 0;
+    if (stride < 1) stride = 1;
+    return 1 + (T - span + stride - 1) / stride;
+}
+TRP_HD u64 chunk_count(u64 T, const DevCfg& cfg) {
+    if (T == 0) return 0;
+    if (T <= cfg.max_window_tokens) return 1;
+    u64 n = 0;
+    for (u32 k = 0; k < cfg.n_overlaps; k++) n += chunk_windows(T, cfg.max_window_tokens, cfg.overlaps[k]);
+    if (cfg.summary_fallback_tokens > 0) n += 1;
+    return n;
+}
+TRP_HD ChunkDesc chunk_at(u64 T, u64 j, u32 record, const DevCfg& cfg) {
+    ChunkDesc c = {record, 0, 0, 0, 0, 0, 0, 0};
+    if (T <= cfg.max_window_tokens) {
+        c.span = (u32)T;
+        c.tok_end = (u32)T;
+        return c;
+    }
+    u64 span = cfg.max_window_tokens;
+    for (u32 k = 0; k < cfg.n_overlaps; k++) {
+        u64 ov = cfg.overlaps[k];
+        u64 w = chunk_windows(T, span, ov);
+        if (j < w) {
+            u64 stride = span > ov ? span - ov : 0;
+            if (stride < 1) stride = 1;
+            u64 start = j * stride;
+            u64 end = start + span < T ? start + span : T;
+            c.index = (u32)j;
+            c.overlap = (u32)ov;
+            c.span = (u32)span;
+            c.tok_begin = (u32)start;
+            c.tok_end = (u32)end;
+            return c;
+        }
+        j -= w;
+    }
+    u64 cap = cfg.summary_fallback_tokens < cfg.max_window_tokens ? cfg.summary_fallback_tokens
+                                                                   : cfg.max_window_tokens;
+    if (cap < 1) cap = 1;
+    c.kind = 1;
+    c.tok_end = (u32)(T < cap ? T : cap);
+    return c;
+}
+
+// ---- serial solver for one digit-heavy line (gate 3, denoiser_preprocessor.rs:70-140) ---------------
+// Memory-free restatement: a token is kept when its distance (in tokens) to the nearest
+// alphabetic-bearing token is <= K, K being the number of accepted waves.  The line is walked gap
+// by gap (a gap = the tokens between two alphabetic-bearing tokens); each gap is walked twice, first
+// for its length, then with every token's distance known.
+struct ByteSrc {
+    const u8* p;   // corpus
+    u64 n;         // corpus length
+};
+struct TokInfo {
+    u64 ts, te;   // [ts, te) byte range, te == ts: no token
+    u32 digits;
+    bool alpha;
+};
+TRP_HD u32 char_at(const ByteSrc& s, u64 q, u64 end, int* len, const UniTables& ut) {
+    // class code of the character starting at q (q < end); *len = its byte length
+    u32 b = s.p[q];
+    if (b < 0x80) { *len = 1; return ascii_class(b); }
+    *len = 1;
+    if (b < 0xC0) return 0;
+    u8 tmp[4] = {(u8)b, 0, 0, 0};
+    for (int i = 1; i < 4; i++) tmp[i] = (q + i < end) ? s.p[q + i] : 0;
+    u32 cp;
+    int n = decode_lead(tmp, &cp);
+    if (!n) return 0;
+    *len = n;
+    if (cp_is_ws_high(cp)) return C_WS;
+    if (cp_is_alpha_high(cp, ut.stage1, ut.stage2, ut.stage1_len)) return C_ALPHA;
+    return 0;
+}
+TRP_HD TokInfo next_token(const ByteSrc& s, u64 pos, u64 end, bool table, const UniTables& ut) {
+    TokInfo t;
+    t.digits = 0;
+    t.alpha = false;
+    const u32 sep = C_WS | (table ? C_PIPE : 0u);
+    int len;
+    while (pos < end) {
+        u32 k = char_at(s, pos, end, &len, ut);
+        if (!(k & sep)) break;
+        pos += len;
+    }
+    t.ts = pos;
+    while (pos < end) {
+        u32 k = char_at(s, pos, end, &len, ut);
+        if (k & sep) break;
+        if (k & C_DIGIT) t.digits++;
+        else if (k & C_ALPHA) t.alpha = true;
+        pos += len;
+    }
+    t.te = pos;
+    return t;
+}
+
+// Calls f(token, keep) for every token of the line [p, e) in order.  Pass K = ~0 to get the digit
+// sum / count of the tokens at distance exactly `probe` instead (no callback use).
+template <class F>
+TRP_HD void g3_walk(const ByteSrc& s, u64 p, u64 e, bool table, const UniTables& ut, u64 K, u64 probe,
+                    u64* wave_digits, u64* wave_count, F f) {
+    u64 pos = p;
+    bool left_alpha = false;
+    u64 wd = 0, wc = 0;
+    for (;;) {
+        // first walk: length of the gap and what closes it
+        u64 g = 0, q = pos;
+        TokInfo closer;
+        bool right_alpha = false;
+        for (;;) {
+            closer = next_token(s, q, e, table, ut);
+            if (closer.te == closer.ts) break;
+            if (closer.alpha) { right_alpha = true; break; }
+            g++;
+            q = closer.te;
+        }
+        // second walk: every gap token with its distance
+        q = pos;
+        for (u64 i = 1; i <= g; i++) {
+            TokInfo t = next_token(s, q, e, table, ut);
+            q = t.te;
+            u64 df = left_alpha ? i : ~0ull;
+            u64 db = right_alpha ? g + 1 - i : ~0ull;
+            u64 dist = df < db ? df : db;
+            if (dist == probe) { wd += t.digits; wc++; }
+            f(t, dist <= K);
+        }
+        if (!right_alpha) break;
+        f(closer, true);
+        left_alpha = true;
+        pos = closer.te;
+    }
+    if (wave_digits) *wave_digits = wd;
+    if (wave_count) *wave_count = wc;
+}
+
+struct NoTok {
+    TRP_HD void operator()(const TokInfo&, bool) const {}
+};
+
+// Number of accepted waves for the line [p, e).
+TRP_HD u64 g3_solve_K(const ByteSrc& s, u64 p, u64 e, bool table, float max_ratio, const UniTables& ut) {
+    // seed totals: digits and alphabetic chars of the alphabetic-bearing tokens
+    u64 d = 0, a = 0;
+    {
+        u64 pos = p;
+        int len;
+        for (;;) {
+            TokInfo t = next_token(s, pos, e, table, ut);
+            if (t.te == t.ts) break;
+            if (t.alpha) {
+                d += t.digits;
+                for (u64 q = t.ts; q < t.te; q += len)
+                    if (char_at(s, q, t.te, &len, ut) & C_ALPHA) a++;
+            }
+            pos = t.te;
+        }
+    }
+    u64 K = 0;
+    for (u64 k = 1;; k++) {
+        u64 wd, wc;
+        g3_walk(s, p, e, table, ut, 0, k, &wd, &wc, NoTok());
+        if (wc == 0) break;
+        if (ratio_exceeds64(d + wd, a, max_ratio)) break;
+        d += wd;
+        K = k;
+    }
+    return K;
+}
+
+}  // namespace trp

@@ -1,0 +1,311 @@
+// Host simulator of the GPU algorithm (development/test aid, not part of the shipped library).
+//
+// Runs the per-block functions of trp_lane.h - the very code the HIP kernels execute per lane - and
+// replaces the wave/workgroup/tile scans by sequential folds with the same monoid operators, tile by
+// tile, so that the bitmask formulation (summaries, carries, plan, gate-3 solver) can be compared
+// with the CPU oracle on machines without a GPU.  The interpretation of the finished plan (byte
+// compaction, token table) is written here in the most direct way possible.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "trp_lane.h"
+
+#define TRP_TABLE_QUAL static const
+#include "unicode_tables.inc"
+
+using namespace trp;
+
+extern "C" {
+
+struct sim_config {
+    uint8_t denoise_enabled;
+    uint8_t strip_markdown;
+    float max_digit_ratio;
+    uint32_t max_window_tokens;
+    const uint32_t* overlaps;
+    uint32_t n_overlaps;
+    uint32_t summary_fallback_tokens;
+};
+
+struct sim_result {
+    uint8_t* denoised;
+    uint64_t* denoised_offsets;
+    uint8_t* dropped;
+    uint32_t* tok_start;
+    uint32_t* tok_len;
+    uint64_t* tok_offsets;
+    ChunkDesc* chunks;
+    uint64_t* chunk_offsets;
+    uint64_t n_records, n_denoised, n_tokens, n_chunks;
+};
+
+int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const sim_config* scfg,
+                  sim_result* out, int tile_blocks);
+void trp_sim_free(sim_result* r);
+int trp_sim_check_monoids(unsigned seed, int iters);
+}
+
+static DevCfg to_dev(const sim_config* c) {
+    DevCfg d;
+    memset(&d, 0, sizeof(d));
+    d.denoise_enabled = c->denoise_enabled;
+    d.strip_markdown = c->strip_markdown;
+    d.max_digit_ratio = c->max_digit_ratio;
+    d.max_window_tokens = c->max_window_tokens;
+    d.n_overlaps = c->n_overlaps > MAX_OVERLAPS ? MAX_OVERLAPS : c->n_overlaps;
+    d.summary_fallback_tokens = c->summary_fallback_tokens;
+    for (u32 i = 0; i < d.n_overlaps; i++) d.overlaps[i] = c->overlaps[i];
+    return d;
+}
+
+namespace {
+struct PlanBits {
+    std::vector<Plan>* plan;
+    void set(u64 q, bool c, bool tok, int prefix) {   // prefix: 0 none, 1 ' ', 2 '\n'
+        Plan& p = (*plan)[q / 64];
+        u64 b = bit((int)(q % 64));
+        if (c) p.C |= b;
+        if (tok) p.TOK |= b;
+        if (prefix == 1) p.PSP |= b;
+        if (prefix == 2) p.PNL |= b;
+    }
+    void clear_marker(u64 q) {
+        Plan& p = (*plan)[q / 64];
+        u64 b = ~bit((int)(q % 64));
+        p.TOK &= b;
+        p.PSP &= b;
+        p.PNL &= b;
+    }
+};
+}  // namespace
+
+int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const sim_config* scfg,
+                  sim_result* out, int tile_blocks) {
+    DevCfg cfg = to_dev(scfg);
+    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN};
+    const u64 N = offsets[R];
+    const u64 nB = (N + 63) / 64;
+    if (tile_blocks <= 0) tile_blocks = TILE_BLOCKS;
+    std::vector<u8> pad(N + 2 * HALO + 64, 0);
+    if (N) memcpy(pad.data() + HALO, bytes, N);
+    const u8* base = pad.data() + HALO;
+    std::vector<u64> RSw(nB + 1, 0);
+    for (u64 r = 0; r < R; r++)
+        if (offsets[r] < N) RSw[offsets[r] / 64] |= bit((int)(offsets[r] % 64));
+    auto rs_at = [&](u64 q) -> bool { return q < N && ((RSw[q / 64] >> (q % 64)) & 1); };
+
+    std::vector<Plan> plan(nB + 1, Plan{0, 0, 0, 0});
+    std::vector<Cls> cls(nB);
+    std::vector<u64> Vm(nB);
+    for (u64 b = 0; b < nB; b++) {
+        u64 p = b * 64;
+        int nvalid = (int)((N - p) < 64 ? (N - p) : 64);
+        cls[b] = classify_block(base + p, nvalid, ut);
+        Vm[b] = below(nvalid);
+    }
+
+    if (cfg.denoise_enabled) {
+        std::vector<Derived> der(nB);
+        std::vector<J> jl(nB);
+        for (u64 b = 0; b < nB; b++) {
+            u64 p = b * 64;
+            bool next_nl = (p + 64 < N) && base[p + 64] == '\n' && !rs_at(p + 64);
+            bool pt = prev_is_term(p > 0, p > 0 ? base[p - 1] : 0, true, base[p], rs_at(p));
+            der[b] = derive(cls[b], Vm[b], RSw[b], next_nl, pt);
+            jl[b] = lane_J(cls[b], der[b]);
+        }
+        // tile summaries, then per-lane prefixes/suffixes through the tile level (as on the device)
+        u64 nT = (nB + tile_blocks - 1) / tile_blocks;
+        std::vector<J> SA(nT);
+        for (u64 t = 0; t < nT; t++) {
+            J acc = j_identity();
+            for (u64 b = t * tile_blocks; b < nB && b < (t + 1) * tile_blocks; b++) acc = j_combine(acc, jl[b]);
+            SA[t] = acc;
+        }
+        for (u64 t = 0; t < nT; t++) {
+            // look-back to the start of the record that covers the first byte of the tile
+            J P = j_identity();
+            for (u64 u = t; u-- > 0;) {
+                P = j_combine(SA[u], P);
+                if (P.g & G_RS) break;
+            }
+            // look-ahead to the next line start
+            S X = s_identity();
+            for (u64 u = t + 1; u < nT; u++) {
+                X = s_combine(X, s_from_J(SA[u]));
+                if (X.has_ls) break;
+            }
+            u64 b0 = t * tile_blocks, b1 = (t + 1) * tile_blocks < nB ? (t + 1) * tile_blocks : nB;
+            std::vector<S> suf(b1 - b0);
+            S acc = X;
+            for (u64 b = b1; b-- > b0;) {
+                suf[b - b0] = acc;
+                acc = s_combine(s_from_J(jl[b]), acc);
+            }
+            J pre = P;
+            for (u64 b = b0; b < b1; b++) {
+                bool next_rs = ((b + 1) * 64 >= N) || rs_at((b + 1) * 64);
+                LaneCarry k = carry_from(pre, suf[b - b0], next_rs);
+                plan[b] = plan_block(cls[b], der[b], k, cfg);
+                pre = j_combine(pre, jl[b]);
+            }
+        }
+        // pending digit-heavy lines (markers): solve serially
+        ByteSrc src = {base, N};
+        PlanBits pb = {&plan};
+        for (u64 b = 0; b < nB; b++) {
+            u64 marks = plan[b].TOK & ~plan[b].C;
+            while (marks) {
+                int j = ctz(marks);
+                marks &= marks - 1;
+                u64 p = b * 64 + j;
+                bool table = (plan[b].PSP >> j) & 1, rab = (plan[b].PNL >> j) & 1;
+                // record end
+                u64 lo = 0, hi = R;   // last r with offsets[r] <= p
+                while (lo < hi) {
+                    u64 mid = (lo + hi) / 2;
+                    if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid;
+                }
+                u64 rec_end = offsets[lo + 1];
+                u64 e = p;
+                while (e < rec_end && base[e] != '\n' && base[e] != '\r') e++;
+                u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
+                pb.clear_marker(p);
+                bool first = true;
+                g3_walk(src, p, e, table, ut, K, ~0ull - 1, nullptr, nullptr,
+                        [&](const TokInfo& t, bool keep) {
+                            if (!keep) return;
+                            for (u64 q = t.ts; q < t.te; q++)
+                                pb.set(q, true, true, q == t.ts ? (first ? (rab ? 2 : 0) : 1) : 0);
+                            first = false;
+                        });
+            }
+        }
+    } else {
+        for (u64 b = 0; b < nB; b++) plan[b] = plan_passthrough(cls[b], Vm[b]);
+    }
+
+    // interpret the plan
+    std::vector<u8> den;
+    std::vector<u32> ts, tl;
+    std::vector<u64> doff(R + 1), toff(R + 1);
+    u64 r = 0;
+    bool prev_tok = false;
+    u64 cur_start_out = 0, cur_start_in = 0;
+    for (u64 q = 0; q <= N; q++) {
+        bool c = false, tok = false;
+        int j = (int)(q % 64);
+        if (q < N) {
+            const Plan& p = plan[q / 64];
+            c = (p.C >> j) & 1;
+            tok = c && ((p.TOK >> j) & 1);
+        }
+        if (prev_tok && (q == N || !tok || rs_at(q))) {   // the open token ended at q-1
+            ts.push_back((u32)cur_start_out);
+            tl.push_back((u32)(q - cur_start_in));
+            prev_tok = false;
+        }
+        while (r < R && offsets[r] == q) {
+            doff[r] = cfg.denoise_enabled ? den.size() : q;
+            toff[r] = ts.size();
+            r++;
+        }
+        if (q == N) break;
+        if (c) {
+            const Plan& p = plan[q / 64];
+            if (cfg.denoise_enabled) {
+                if ((p.PSP >> j) & 1) den.push_back(' ');
+                else if ((p.PNL >> j) & 1) den.push_back('\n');
+            }
+            if (tok && !prev_tok) {
+                prev_tok = true;
+                cur_start_in = q;
+                cur_start_out = cfg.denoise_enabled ? den.size() : q;
+            }
+            if (cfg.denoise_enabled) den.push_back(base[q]);
+        }
+    }
+    while (r < R) { doff[r] = cfg.denoise_enabled ? den.size() : N; toff[r] = ts.size(); r++; }
+    doff[R] = cfg.denoise_enabled ? den.size() : N;
+    toff[R] = ts.size();
+
+    memset(out, 0, sizeof(*out));
+    out->n_records = R;
+    u64 D = cfg.denoise_enabled ? den.size() : N;
+    out->n_denoised = D;
+    out->n_tokens = ts.size();
+    out->denoised = (u8*)malloc(D ? D : 1);
+    if (D) memcpy(out->denoised, cfg.denoise_enabled ? den.data() : bytes, D);
+    out->denoised_offsets = (u64*)malloc((R + 1) * sizeof(u64));
+    out->tok_offsets = (u64*)malloc((R + 1) * sizeof(u64));
+    out->chunk_offsets = (u64*)malloc((R + 1) * sizeof(u64));
+    out->dropped = (u8*)malloc(R ? R : 1);
+    memcpy(out->denoised_offsets, doff.data(), (R + 1) * sizeof(u64));
+    memcpy(out->tok_offsets, toff.data(), (R + 1) * sizeof(u64));
+    out->tok_start = (u32*)malloc((ts.size() ? ts.size() : 1) * sizeof(u32));
+    out->tok_len = (u32*)malloc((ts.size() ? ts.size() : 1) * sizeof(u32));
+    if (!ts.empty()) {
+        memcpy(out->tok_start, ts.data(), ts.size() * sizeof(u32));
+        memcpy(out->tok_len, tl.data(), tl.size() * sizeof(u32));
+    }
+    u64 C = 0;
+    for (u64 i = 0; i < R; i++) {
+        out->chunk_offsets[i] = C;
+        C += chunk_count(toff[i + 1] - toff[i], cfg);
+        out->dropped[i] = cfg.denoise_enabled && doff[i + 1] == doff[i];
+    }
+    out->chunk_offsets[R] = C;
+    out->n_chunks = C;
+    out->chunks = (ChunkDesc*)malloc((C ? C : 1) * sizeof(ChunkDesc));
+    for (u64 i = 0; i < R; i++) {
+        u64 T = toff[i + 1] - toff[i];
+        u64 n = out->chunk_offsets[i + 1] - out->chunk_offsets[i];
+        for (u64 j = 0; j < n; j++) out->chunks[out->chunk_offsets[i] + j] = chunk_at(T, j, (u32)i, cfg);
+    }
+    return 0;
+}
+
+void trp_sim_free(sim_result* r) {
+    free(r->denoised); free(r->denoised_offsets); free(r->dropped); free(r->tok_start);
+    free(r->tok_len); free(r->tok_offsets); free(r->chunks); free(r->chunk_offsets);
+    memset(r, 0, sizeof(*r));
+}
+
+// Brute-force associativity check of the two monoids on random elements; returns the number of
+// violations.
+static u32 rnd(unsigned* s) { *s = *s * 1664525u + 1013904223u; return *s >> 8; }
+static LineSum rnd_ls(unsigned* s) {
+    LineSum l;
+    l.d = rnd(s) % 4; l.a = rnd(s) % 3; l.p = rnd(s) % 3;
+    u32 first = rnd(s) % 3, last = first ? 1 + rnd(s) % 2 : 0;
+    l.f = first | (last << 2) | ((first == 2 || last == 2 || (first && rnd(s) % 2)) ? 16u : 0u);
+    return l;
+}
+static J rnd_J(unsigned* s) {
+    J j;
+    j.head = rnd_ls(s);
+    j.g = 0;
+    if (rnd(s) % 2) { j.g |= G_LS; j.tail = rnd_ls(s); j.g |= (rnd(s) % 2) ? G_C0 : 0; j.g |= (rnd(s) % 2) ? G_C1 : 0; }
+    else j.tail = ls_empty();
+    if (rnd(s) % 2) { j.g |= G_RS | G_LS; j.g &= ~G_C1; if (rnd(s) % 2) j.g |= G_AH; if (rnd(s) % 2) j.g |= G_AT; }
+    else if (rnd(s) % 2) j.g |= G_AH | G_AT;
+    return j;
+}
+static bool eq_ls(const LineSum& a, const LineSum& b) { return a.d == b.d && a.a == b.a && a.p == b.p && a.f == b.f; }
+int trp_sim_check_monoids(unsigned seed, int iters) {
+    int bad = 0;
+    for (int i = 0; i < iters; i++) {
+        J a = rnd_J(&seed), b = rnd_J(&seed), c = rnd_J(&seed);
+        J l = j_combine(j_combine(a, b), c), r = j_combine(a, j_combine(b, c));
+        if (!(eq_ls(l.head, r.head) && eq_ls(l.tail, r.tail) && l.g == r.g)) bad++;
+        S x = s_from_J(a), y = s_from_J(b), z = s_from_J(c);
+        S sl = s_combine(s_combine(x, y), z), sr = s_combine(x, s_combine(y, z));
+        if (!(eq_ls(sl.head, sr.head) && sl.has_ls == sr.has_ls)) bad++;
+        J ia = j_combine(j_identity(), a), ai = j_combine(a, j_identity());
+        if (!(eq_ls(ia.head, a.head) && eq_ls(ia.tail, a.tail) && ia.g == a.g)) bad++;
+        if (!(eq_ls(ai.head, a.head) && eq_ls(ai.tail, a.tail) && ai.g == a.g)) bad++;
+    }
+    return bad;
+}
