@@ -1,0 +1,161 @@
+/*
+ * triplets_amd - C ABI of the MI355X (gfx950) implementation of the `triplets` crate's per-record
+ * text preprocessing path: OCR/markdown denoising -> whitespace tokenisation -> sliding-window
+ * chunking, over MANY records packed into one contiguous byte buffer plus an offsets array.
+ *
+ * Nothing like this batched entry point exists in the reference (it processes one section per
+ * call, on the CPU); each declaration below cites the reference interface whose semantics it
+ * reproduces bit for bit.  Paths are relative to the reference checkout.
+ *
+ * Conventions
+ *   - every function returns an int status: TRP_OK (0) or a negative TRP_E_* code; the text of the
+ *     last error of the calling thread is available from trp_last_error().
+ *   - text must be valid UTF-8 (the reference takes Rust `&str`); record boundaries never split a
+ *     character.  Malformed input never faults but its classification is unspecified.
+ *   - a batch holds at most TRP_MAX_BATCH_BYTES bytes and 2^32-2 records; callers split larger
+ *     corpora by record range (records are independent).
+ *   - a trp_ctx is bound to one GPU and one HIP stream and must not be used from two threads at the
+ *     same time; create one context per thread (they are cheap and independent).
+ */
+#ifndef TRIPLETS_AMD_H
+#define TRIPLETS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRP_OK 0
+#define TRP_E_ARG (-1)      /* invalid argument */
+#define TRP_E_HIP (-2)      /* a HIP runtime call failed (no GPU, out of memory, ...) */
+#define TRP_E_TOO_LARGE (-3) /* batch exceeds TRP_MAX_BATCH_BYTES or the record limit */
+
+#define TRP_MAX_BATCH_BYTES 0xFFFF0000ull
+#define TRP_MAX_OVERLAPS 16
+
+typedef struct trp_ctx trp_ctx;
+
+/* DenoiserConfig (src/config.rs:12-42) and the chunking fields of ChunkingStrategy
+ * (src/config.rs:45-71).  Defaults of the reference: enabled=false, max_digit_ratio=0.35,
+ * strip_markdown=true, max_window_tokens=1024, overlap_tokens=[64], summary_fallback_tokens=512. */
+typedef struct {
+    uint8_t denoise_enabled;
+    uint8_t strip_markdown;
+    float max_digit_ratio;
+    uint32_t max_window_tokens;
+    const uint32_t* overlaps; /* host pointer, n_overlaps entries (<= TRP_MAX_OVERLAPS) */
+    uint32_t n_overlaps;
+    uint32_t summary_fallback_tokens;
+} trp_config;
+
+/* One RecordChunk view (src/data.rs:130-174, built at src/chunking/sliding_window.rs:45-111) minus
+ * its owned strings.  kind 0 = ChunkView::Window{index,overlap,span}, kind 1 =
+ * ChunkView::SummaryFallback{strategy:"head"}.  The chunk covers tokens [tok_begin, tok_end) of its
+ * record (relative to the record's first token); tokens_estimate = tok_end - tok_begin. */
+typedef struct {
+    uint32_t record;
+    uint32_t kind;
+    uint32_t index;
+    uint32_t overlap;
+    uint32_t span;
+    uint32_t tok_begin;
+    uint32_t tok_end;
+    uint32_t reserved;
+} trp_chunk;
+
+/* Result of one batch.  All arrays are host memory for trp_preprocess_batch and device memory for
+ * trp_preprocess_batch_device.
+ *   denoised / denoised_offsets[R+1]: the preprocessed text of record r is
+ *       denoised[denoised_offsets[r] .. denoised_offsets[r+1]).  With the denoiser disabled the text
+ *       is the input itself: `denoised` then aliases the caller's input buffer (device variant) or
+ *       is a copy of it (host variant) and denoised_offsets equals the input offsets.
+ *   dropped[R]: 1 where the preprocessor returned None (the section yields no chunks).
+ *   tok_start / tok_len, tok_offsets[R+1]: token k of record r is the byte range
+ *       denoised[tok_start[tok_offsets[r]+k] .. +tok_len[...]) - what
+ *       WhitespaceTokenizer::tokenize returns as &str slices.
+ *   chunks, chunk_offsets[R+1]: the Vec<RecordChunk> of record r, in the reference's order. */
+typedef struct {
+    uint8_t* denoised;
+    uint64_t* denoised_offsets;
+    uint8_t* dropped;
+    uint32_t* tok_start;
+    uint32_t* tok_len;
+    uint64_t* tok_offsets;
+    trp_chunk* chunks;
+    uint64_t* chunk_offsets;
+    uint64_t n_records, n_denoised, n_tokens, n_chunks;
+} trp_result;
+
+/* Duration of one kernel of the last profiled call (see trp_set_profiling). */
+typedef struct {
+    char name[32];
+    float ms;
+} trp_kernel_time;
+
+/* Create / destroy a context on GPU `device` (a HIP device ordinal).  Fails with TRP_E_HIP when no
+ * usable gfx950 device is present: there is no CPU fallback. */
+int trp_create(int device, trp_ctx** out);
+void trp_destroy(trp_ctx* ctx);
+const char* trp_last_error(void);
+/* The hipStream_t the context launches on (as void*), for callers that order their own work. */
+void* trp_stream(trp_ctx* ctx);
+
+/* Batched path over host memory: copies the batch to the GPU, runs the kernels and copies every
+ * result array back into buffers owned by the library (release them with trp_result_free).
+ * Replaces, for all records at once: the preprocessor fold + tokenizer + window loop of
+ * SlidingWindowChunker::materialize (src/chunking/sliding_window.rs:11-117), i.e. per record
+ * DenoiserPreprocessor::process / denoise_text (src/preprocessor/backends/denoiser_preprocessor.rs:
+ * 221-268, 303-306), WhitespaceTokenizer::tokenize (src/tokenizer.rs:57-59) and the window and
+ * summary-fallback arithmetic (sliding_window.rs:40-115).
+ * offsets has n_records+1 entries, offsets[0] = 0, non-decreasing; record r is
+ * bytes[offsets[r] .. offsets[r+1]). */
+int trp_preprocess_batch(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets,
+                         uint64_t n_records, const trp_config* cfg, trp_result* out);
+void trp_result_free(trp_result* r);
+
+/* Same path with the batch already resident in GPU memory (16-byte aligned `d_bytes`, device
+ * `d_offsets`).  The result arrays are device pointers into buffers owned by the context; they stay
+ * valid until the next call on this context.  The call returns after the kernels have completed
+ * (the totals in `out` are read back). */
+int trp_preprocess_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                                uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
+                                trp_result* out);
+
+/* Copy `bytes` bytes of a device array of the last result into host memory (ordered on the context's
+ * stream, returns when the copy is complete). */
+int trp_copy_to_host(trp_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* Chunk text of the last device-resident batch, rendered as the reference does
+ * (sliding_window.rs:44, :67, :95-100): tokens joined by one space, or the preprocessed text verbatim
+ * for a record with a single window.  Produces device arrays: text bytes of all chunks concatenated
+ * and text_offsets[n_chunks+1]. */
+int trp_materialize_chunk_text_device(trp_ctx* ctx, uint8_t** d_text, uint64_t** d_text_offsets,
+                                      uint64_t* n_text_bytes);
+
+/* Single-record conveniences mirroring the reference's public functions (each runs a batch of one).
+ * trp_denoise: denoise_text (denoiser_preprocessor.rs:221): returns 1 for Some(text) with a malloc'd
+ *   copy in *out (free with trp_free), 0 for None, negative on error.
+ * trp_tokenize: WhitespaceTokenizer::tokenize (tokenizer.rs:57): (start,len) pairs into `text`.
+ * trp_token_count: WhitespaceTokenizer::token_count (tokenizer.rs:62).
+ * trp_chunk_section: SlidingWindowChunker::materialize (sliding_window.rs:11) for one section. */
+int trp_denoise(trp_ctx* ctx, const uint8_t* text, size_t len, const trp_config* cfg, uint8_t** out,
+                size_t* out_len);
+int trp_tokenize(trp_ctx* ctx, const uint8_t* text, size_t len, uint32_t** starts, uint32_t** lens,
+                 size_t* n_tokens);
+int trp_token_count(trp_ctx* ctx, const uint8_t* text, size_t len, size_t* n_tokens);
+int trp_chunk_section(trp_ctx* ctx, const uint8_t* text, size_t len, const trp_config* cfg,
+                      trp_result* out);
+void trp_free(void* p);
+
+/* Per-kernel timing with HIP events on the context's stream.  When on, the next batch call records
+ * an event pair around every kernel; trp_get_profile returns the durations of that call (number of
+ * entries, at most cap). */
+int trp_set_profiling(trp_ctx* ctx, int on);
+int trp_get_profile(trp_ctx* ctx, trp_kernel_time* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

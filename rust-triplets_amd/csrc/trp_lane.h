@@ -156,6 +156,20 @@ TRP_HD Cls classify_block(const u8* blk, int nvalid, const UniTables& ut) {
     return c;
 }
 
+// Is the byte at q[0] part of a whitespace character?  q[-3..3] must be readable.
+TRP_HD bool byte_is_ws(const u8* q) {
+    u32 b = q[0];
+    if (b < 0x80) return (ascii_class(b) & C_WS) != 0;
+    u32 cp;
+    if (b >= 0xC0) return decode_lead(q, &cp) && cp_is_ws_high(cp);
+    for (int k = 1; k <= 3; k++) {
+        u32 l = q[-k];
+        if (l >= 0xC0) return decode_lead(q - k, &cp) > k && cp_is_ws_high(cp);
+        if (l < 0x80) return false;
+    }
+    return false;
+}
+
 // ---- line structure ------------------------------------------------------------------------------
 struct Derived {
     u64 V;     // bytes that exist (below the end of the corpus)

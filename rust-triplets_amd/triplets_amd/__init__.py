@@ -1,0 +1,399 @@
+"""Host-side mirror (Python, ctypes) of the reference's denoiser / tokenizer / chunker surface on top
+of the C ABI of libtriplets_amd.so (HIP kernels for gfx950).
+
+Names and argument meaning follow the reference crate (paths relative to its checkout):
+  DenoiserConfig, ChunkingStrategy                       src/config.rs:12-119
+  denoise_text, DenoiserPreprocessor.process             src/preprocessor/backends/denoiser_preprocessor.rs:221, :303
+  WhitespaceTokenizer.tokenize / token_count             src/tokenizer.rs:55-65
+  SlidingWindowChunker.materialize                       src/chunking/sliding_window.rs:11-117
+plus the batched entry point `preprocess_batch` (many records in one packed buffer).
+
+There is no CPU fallback: importing works anywhere, but every call needs the built shared library
+and a GPU, and raises TripletsAmdError otherwise.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtriplets_amd.so")
+
+TRP_OK = 0
+
+
+class TripletsAmdError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("denoise_enabled", C.c_uint8), ("strip_markdown", C.c_uint8),
+                ("max_digit_ratio", C.c_float), ("max_window_tokens", C.c_uint32),
+                ("overlaps", C.POINTER(C.c_uint32)), ("n_overlaps", C.c_uint32),
+                ("summary_fallback_tokens", C.c_uint32)]
+
+
+class _Chunk(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("record", "kind", "index", "overlap", "span", "tok_begin", "tok_end", "reserved")]
+
+
+class _Result(C.Structure):
+    _fields_ = [("denoised", C.c_void_p), ("denoised_offsets", C.c_void_p), ("dropped", C.c_void_p),
+                ("tok_start", C.c_void_p), ("tok_len", C.c_void_p), ("tok_offsets", C.c_void_p),
+                ("chunks", C.c_void_p), ("chunk_offsets", C.c_void_p),
+                ("n_records", C.c_uint64), ("n_denoised", C.c_uint64), ("n_tokens", C.c_uint64),
+                ("n_chunks", C.c_uint64)]
+
+
+class _KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms", C.c_float)]
+
+
+CHUNK_DTYPE = np.dtype([(n, "<u4") for n in
+                        ("record", "kind", "index", "overlap", "span", "tok_begin", "tok_end",
+                         "reserved")])
+
+EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_preprocess_batch",
+           "trp_result_free", "trp_preprocess_batch_device", "trp_copy_to_host",
+           "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
+           "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile"]
+
+_lib = None
+
+
+def load_library():
+    """Load libtriplets_amd.so (built in-tree by `make -C rust-triplets_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TripletsAmdError("HIP library not built: %s is missing (run __graft_entry__.build())"
+                               % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.trp_last_error.restype = C.c_char_p
+    L.trp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.trp_destroy.argtypes = [C.c_void_p]
+    L.trp_stream.restype = C.c_void_p
+    L.trp_stream.argtypes = [C.c_void_p]
+    L.trp_preprocess_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                       C.POINTER(_Config), C.POINTER(_Result)]
+    L.trp_result_free.argtypes = [C.POINTER(_Result)]
+    L.trp_preprocess_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                              C.c_uint64, C.POINTER(_Config), C.POINTER(_Result)]
+    L.trp_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.trp_materialize_chunk_text_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p),
+                                                    C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.trp_denoise.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(_Config),
+                              C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.trp_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.trp_token_count.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.trp_chunk_section.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(_Config),
+                                    C.POINTER(_Result)]
+    L.trp_free.argtypes = [C.c_void_p]
+    L.trp_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.trp_get_profile.argtypes = [C.c_void_p, C.POINTER(_KernelTime), C.c_int]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise TripletsAmdError("triplets_amd error %d: %s" % (rc, load_library().trp_last_error().decode()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# configuration types (src/config.rs)
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class DenoiserConfig:
+    enabled: bool = False
+    max_digit_ratio: float = 0.35
+    strip_markdown: bool = True
+
+
+@dataclass
+class ChunkingStrategy:
+    max_window_tokens: int = 1024
+    overlap_tokens: List[int] = field(default_factory=lambda: [64])
+    summary_fallback_weight: float = 0.35
+    summary_fallback_tokens: int = 512
+    chunk_weight_floor: float = 0.1
+    preprocessors: list = field(default_factory=list)
+
+    def register_preprocessor(self, p):
+        self.preprocessors.append(p)
+        return self
+
+
+def _make_cfg(den: DenoiserConfig, st: ChunkingStrategy):
+    ov = list(st.overlap_tokens)
+    arr = (C.c_uint32 * max(1, len(ov)))(*ov)
+    cfg = _Config(int(den.enabled), int(den.strip_markdown), float(den.max_digit_ratio),
+                  int(st.max_window_tokens), C.cast(arr, C.POINTER(C.c_uint32)), len(ov),
+                  int(st.summary_fallback_tokens))
+    cfg._keep = arr
+    return cfg
+
+
+# ---------------------------------------------------------------------------------------------------
+# context and batched entry points
+# ---------------------------------------------------------------------------------------------------
+class BatchResult:
+    """Host copy of one batch result (numpy arrays)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def record_text(self, r) -> bytes:
+        return self.denoised[int(self.denoised_offsets[r]):int(self.denoised_offsets[r + 1])].tobytes()
+
+    def tokens(self, r) -> List[bytes]:
+        t0, t1 = int(self.tok_offsets[r]), int(self.tok_offsets[r + 1])
+        return [self.denoised[int(s):int(s) + int(n)].tobytes()
+                for s, n in zip(self.tok_start[t0:t1], self.tok_len[t0:t1])]
+
+    def chunk_text(self, c) -> bytes:
+        ch = self.chunks[c]
+        rec = int(ch["record"])
+        t0 = int(self.tok_offsets[rec])
+        nt = int(self.tok_offsets[rec + 1]) - t0
+        if (int(self.chunk_offsets[rec + 1] - self.chunk_offsets[rec]) == 1 and ch["kind"] == 0
+                and int(ch["tok_end"]) - int(ch["tok_begin"]) == nt):
+            return self.record_text(rec)
+        parts = []
+        for k in range(int(ch["tok_begin"]), int(ch["tok_end"])):
+            s = int(self.tok_start[t0 + k])
+            parts.append(self.denoised[s:s + int(self.tok_len[t0 + k])].tobytes())
+        return b" ".join(parts)
+
+
+class DeviceResult:
+    """Device pointers (ints) + totals of the last device-resident batch of a Context."""
+
+    def __init__(self, ctx, res):
+        self.ctx = ctx
+        for name, _ in _Result._fields_:
+            setattr(self, name, getattr(res, name) or 0)
+
+    def fetch(self, name, count, dtype):
+        dtype = np.dtype(dtype)
+        out = np.empty(int(count), dtype=dtype)
+        if count:
+            _check(load_library().trp_copy_to_host(self.ctx._h, out.ctypes.data, getattr(self, name),
+                                                   out.nbytes))
+        return out
+
+    def to_host(self, denoised_from=None) -> BatchResult:
+        R = int(self.n_records)
+        return BatchResult(
+            denoised=self.fetch("denoised", self.n_denoised, np.uint8),
+            denoised_offsets=self.fetch("denoised_offsets", R + 1, np.uint64),
+            dropped=self.fetch("dropped", R, np.uint8),
+            tok_start=self.fetch("tok_start", self.n_tokens, np.uint32),
+            tok_len=self.fetch("tok_len", self.n_tokens, np.uint32),
+            tok_offsets=self.fetch("tok_offsets", R + 1, np.uint64),
+            chunks=self.fetch("chunks", self.n_chunks, CHUNK_DTYPE),
+            chunk_offsets=self.fetch("chunk_offsets", R + 1, np.uint64),
+            n_records=R, n_denoised=int(self.n_denoised), n_tokens=int(self.n_tokens),
+            n_chunks=int(self.n_chunks))
+
+
+class Context:
+    """One GPU context (one HIP stream).  Not thread-safe: use one per thread."""
+
+    def __init__(self, device: int = 0):
+        L = load_library()
+        h = C.c_void_p()
+        _check(L.trp_create(device, C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if self._h:
+            self._L.trp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return self._L.trp_stream(self._h) or 0
+
+    def preprocess_batch(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
+                         strategy: ChunkingStrategy) -> BatchResult:
+        """Packed batch in host memory -> host result (copies in and out)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        R = len(offsets) - 1
+        cfg = _make_cfg(denoiser, strategy)
+        res = _Result()
+        _check(self._L.trp_preprocess_batch(self._h, data.ctypes.data if data.size else None,
+                                            offsets.ctypes.data, R, C.byref(cfg), C.byref(res)))
+
+        def arr(ptr, n, dt):
+            dt = np.dtype(dt)
+            if not n:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(C.string_at(ptr, int(n) * dt.itemsize), dtype=dt).copy()
+
+        out = BatchResult(
+            denoised=arr(res.denoised, res.n_denoised, np.uint8),
+            denoised_offsets=arr(res.denoised_offsets, R + 1, np.uint64),
+            dropped=arr(res.dropped, R, np.uint8),
+            tok_start=arr(res.tok_start, res.n_tokens, np.uint32),
+            tok_len=arr(res.tok_len, res.n_tokens, np.uint32),
+            tok_offsets=arr(res.tok_offsets, R + 1, np.uint64),
+            chunks=arr(res.chunks, res.n_chunks, CHUNK_DTYPE),
+            chunk_offsets=arr(res.chunk_offsets, R + 1, np.uint64),
+            n_records=R, n_denoised=int(res.n_denoised), n_tokens=int(res.n_tokens),
+            n_chunks=int(res.n_chunks))
+        self._L.trp_result_free(C.byref(res))
+        return out
+
+    def preprocess_batch_device(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int,
+                                denoiser: DenoiserConfig, strategy: ChunkingStrategy) -> DeviceResult:
+        """Packed batch already in GPU memory (raw device pointers) -> device-resident result."""
+        cfg = _make_cfg(denoiser, strategy)
+        res = _Result()
+        _check(self._L.trp_preprocess_batch_device(self._h, d_bytes, d_offsets, n_records, n_bytes,
+                                                   C.byref(cfg), C.byref(res)))
+        return DeviceResult(self, res)
+
+    def materialize_chunk_text(self):
+        """Chunk texts of the last device batch -> (bytes array, offsets[n_chunks+1]) on the host."""
+        t, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.trp_materialize_chunk_text_device(self._h, C.byref(t), C.byref(o), C.byref(n)))
+        return t.value or 0, o.value or 0, int(n.value)
+
+    def set_profiling(self, on: bool):
+        _check(self._L.trp_set_profiling(self._h, int(on)))
+
+    def profile(self):
+        arr = (_KernelTime * 64)()
+        n = _check(self._L.trp_get_profile(self._h, arr, 64))
+        return [(arr[i].name.decode(), float(arr[i].ms)) for i in range(min(n, 64))]
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def pack(records: Sequence[bytes]):
+    """list of bytes -> (uint8 array, uint64 offsets[R+1])"""
+    offs = np.zeros(len(records) + 1, dtype=np.uint64)
+    if len(records):
+        offs[1:] = np.cumsum([len(r) for r in records], dtype=np.uint64)
+    return np.frombuffer(b"".join(records), dtype=np.uint8).copy(), offs
+
+
+def preprocess_batch(records: Sequence[bytes], denoiser: DenoiserConfig = None,
+                     strategy: ChunkingStrategy = None, ctx: Context = None) -> BatchResult:
+    data, offs = pack(records)
+    return (ctx or default_context()).preprocess_batch(data, offs, denoiser or DenoiserConfig(),
+                                                       strategy or ChunkingStrategy())
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-record surface of the reference
+# ---------------------------------------------------------------------------------------------------
+def denoise_text(text: str, config: DenoiserConfig, ctx: Context = None) -> Optional[str]:
+    """denoise_text(text, &config) -> Option<String>"""
+    ctx = ctx or default_context()
+    b = text.encode("utf-8")
+    cfg = _make_cfg(config, ChunkingStrategy())
+    out, n = C.c_void_p(), C.c_size_t()
+    rc = _check(ctx._L.trp_denoise(ctx._h, b, len(b), C.byref(cfg), C.byref(out), C.byref(n)))
+    if rc == 0:
+        return None
+    s = C.string_at(out, n.value) if n.value else b""
+    ctx._L.trp_free(out)
+    return s.decode("utf-8")
+
+
+class DenoiserPreprocessor:
+    """TextPreprocessor implementation (process(&self, &str) -> Option<String>)."""
+
+    def __init__(self, config: DenoiserConfig):
+        self.config = config
+
+    def process(self, text: str, ctx: Context = None) -> Optional[str]:
+        return denoise_text(text, self.config, ctx)
+
+
+class WhitespaceTokenizer:
+    def tokenize(self, text: str, ctx: Context = None) -> List[str]:
+        ctx = ctx or default_context()
+        b = text.encode("utf-8")
+        s, ln, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _check(ctx._L.trp_tokenize(ctx._h, b, len(b), C.byref(s), C.byref(ln), C.byref(n)))
+        starts = np.frombuffer(C.string_at(s, n.value * 4), dtype=np.uint32) if n.value else []
+        lens = np.frombuffer(C.string_at(ln, n.value * 4), dtype=np.uint32) if n.value else []
+        ctx._L.trp_free(s)
+        ctx._L.trp_free(ln)
+        return [b[int(a):int(a) + int(l)].decode("utf-8") for a, l in zip(starts, lens)]
+
+    def token_count(self, text: str, ctx: Context = None) -> int:
+        ctx = ctx or default_context()
+        b = text.encode("utf-8")
+        n = C.c_size_t()
+        _check(ctx._L.trp_token_count(ctx._h, b, len(b), C.byref(n)))
+        return int(n.value)
+
+
+@dataclass
+class ChunkView:
+    kind: str            # "Window" | "SummaryFallback"
+    index: int = 0
+    overlap: int = 0
+    span: int = 0
+    strategy: str = ""
+    weight: float = 0.0
+
+
+@dataclass
+class RecordChunk:
+    record_id: str
+    section_idx: int
+    view: ChunkView
+    text: str
+    tokens_estimate: int
+
+
+class SlidingWindowChunker:
+    """ChunkingAlgorithm implementation: materialize(strategy, record, section_idx, section)."""
+
+    def materialize(self, strategy: ChunkingStrategy, record_id: str, section_idx: int,
+                    section_text: str, ctx: Context = None) -> List[RecordChunk]:
+        den = DenoiserConfig()
+        for p in strategy.preprocessors:
+            if isinstance(p, DenoiserPreprocessor):
+                den = p.config
+            else:
+                raise TripletsAmdError("only DenoiserPreprocessor is implemented on the GPU path")
+        res = preprocess_batch([section_text.encode("utf-8")], den, strategy, ctx)
+        out = []
+        for i in range(res.n_chunks):
+            c = res.chunks[i]
+            if c["kind"] == 0:
+                view = ChunkView("Window", int(c["index"]), int(c["overlap"]), int(c["span"]))
+            else:
+                view = ChunkView("SummaryFallback", strategy="head",
+                                 weight=strategy.summary_fallback_weight)
+            out.append(RecordChunk(record_id, section_idx, view, res.chunk_text(i).decode("utf-8"),
+                                   int(c["tok_end"]) - int(c["tok_begin"])))
+        return out

@@ -1,0 +1,174 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle (bit-exact) on
+the reference's golden vectors, adversarial fuzz corpora and edge cases."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import textgen
+from parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def T():
+    import triplets_amd
+    return triplets_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(T):
+    c = T.Context(0)
+    yield c
+    c.close()
+
+
+def _load(name):
+    with open(os.path.join(G, name), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def _run(T, ctx, recs, cfg_tuple):
+    enabled, ratio, md, mwt, ov, sft = cfg_tuple
+    data, offs = O.pack(recs)
+    exp = O.batch(data, offs, O.make_config(enabled, ratio, md, mwt, tuple(ov), sft))
+    got = ctx.preprocess_batch(data, offs, T.DenoiserConfig(enabled, ratio, md),
+                               T.ChunkingStrategy(max_window_tokens=mwt, overlap_tokens=list(ov),
+                                                  summary_fallback_tokens=sft))
+    return exp, got
+
+
+def test_golden_denoiser_vectors(T, ctx):
+    den = _load("denoiser.json")
+    for case in den["exact"]:
+        cfg = case["config"]
+        out = T.denoise_text(case["input"], T.DenoiserConfig(cfg["enabled"], cfg["max_digit_ratio"],
+                                                             cfg["strip_markdown"]), ctx)
+        assert out == case["expected"], case["ref"]
+    for case in den["property"]:
+        res = T.DenoiserPreprocessor(T.DenoiserConfig(True, 0.35, True)).process(case["input"], ctx)
+        assert res is not None
+        for s in case["contains"]:
+            assert s in res, case["ref"]
+        for s in case["not_contains"]:
+            assert s not in res, case["ref"]
+        if case["line_count"] is not None:
+            assert len(res.split("\n")) == case["line_count"], case["ref"]
+
+
+def test_golden_tokenizer_vectors(T, ctx):
+    tok = _load("tokenizer.json")
+    wt = T.WhitespaceTokenizer()
+    for case in tok["tokenize"]:
+        assert wt.tokenize(case["input"], ctx) == case["tokens"], case["ref"]
+        assert wt.token_count(case["input"], ctx) == len(case["tokens"]), case["ref"]
+
+
+def test_golden_chunker_vectors(T, ctx):
+    for case in _load("chunker.json")["cases"]:
+        st = T.ChunkingStrategy(max_window_tokens=case["max_window_tokens"],
+                                overlap_tokens=list(case["overlaps"]),
+                                summary_fallback_tokens=case["summary_fallback_tokens"])
+        if case["denoise"]:
+            d = case["denoise"]
+            st.register_preprocessor(T.DenoiserPreprocessor(
+                T.DenoiserConfig(d["enabled"], d["max_digit_ratio"], d["strip_markdown"])))
+        chunks = T.SlidingWindowChunker().materialize(st, "r1", 0, case["text"], ctx)
+        views = [[0 if c.view.kind == "Window" else 1, c.view.index, c.view.overlap, c.view.span]
+                 for c in chunks]
+        assert views == [v[:4] for v in case["views"]], case["ref"]
+        assert [c.tokens_estimate for c in chunks] == [v[5] - v[4] for v in case["views"]], case["ref"]
+        if "texts" in case:
+            assert [c.text for c in chunks] == case["texts"], case["ref"]
+        a = case["asserted"]
+        if "window_texts" in a:
+            assert [c.text for c in chunks if c.view.kind == "Window"] == a["window_texts"]
+
+
+def test_example_dataset_config_a(T, ctx):
+    """multi_source_demo configuration: default chunking, no denoiser, the twelve example files."""
+    import ctypes as C
+    L = O.lib()
+    sections = []
+    for name, raw in sorted(_load("example_dataset.json")["files"].items()):
+        b = raw.encode()
+        buf = C.create_string_buffer(len(b) + 1)
+        n = L.orc_normalize_inline_whitespace(b, len(b), buf)
+        norm = buf.raw[:n]
+        sections += [norm.split(b".")[0].strip(), norm]
+    exp, got = _run(T, ctx, sections, (False, 0.35, True, 1024, (64,), 512))
+    assert_same(exp, got, sections, "config A")
+    assert got.n_chunks == len(sections)
+    for r, text in enumerate(sections):
+        assert got.chunk_text(r) == text
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_enabled(T, ctx, seed):
+    recs = textgen.corpus(seed, 400)
+    cfg = (True, [0.35, 0.2, 0.5, 0.0, 1.0][seed % 5], seed % 3 != 0, [1024, 16, 5, 0, 1][seed % 5],
+           [(64,), (2, 3), (0,), (), (7, 1, 100)][seed % 5], [512, 4, 0, 3, 1][(seed // 2) % 5])
+    exp, got = _run(T, ctx, recs, cfg)
+    assert_same(exp, got, recs, "fuzz%d" % seed)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_disabled(T, ctx, seed):
+    recs = textgen.corpus(100 + seed, 400)
+    exp, got = _run(T, ctx, recs, (False, 0.35, True, [1024, 7][seed % 2], (64, 3), 5))
+    assert_same(exp, got, recs, "dis%d" % seed)
+
+
+def test_edge_batches(T, ctx):
+    cfgs = [(True, 0.35, True, 4, (1,), 2), (False, 0.35, True, 4, (1,), 2)]
+    cases = ([], [b""], [b"", b"", b""], [b"\n"], [b"a"], [b"a", b"", b"b\r", b"\nc"],
+             [b"x" * 64, b"y" * 64], [b"word " * 100 + b"\r", b"\n42 42 42 a"], [b"|" * 200],
+             [b" " * 130 + b"a" + b" " * 130], [b"| a |" + b" " * 70 + b"| b |"],
+             ["a　".encode() * 40], [("1 " * 40 + "w ").encode() * 5],
+             [b"tok" * 30000],                                   # one token across several tiles
+             [b"a " * 9000, b"b" * 16384, b"", b"c d"],          # records ending on tile edges
+             [b"x" * 16383 + b"\r", b"\ny"], [b"x" * 16383 + b"\r\ny"],
+             [("| " + "cell " * 4000 + "|").encode()],           # table row across tiles
+             [("9 " * 9000 + "word " + "7 " * 9000).encode()])   # digit-heavy line across tiles
+    for cfg in cfgs:
+        for recs in cases:
+            exp, got = _run(T, ctx, recs, cfg)
+            assert_same(exp, got, recs, repr(recs)[:60])
+
+
+def test_long_records_and_multiple_overlaps(T, ctx):
+    import random
+    rng = random.Random(7)
+    recs = [textgen.long_line_record(rng, 40000), b"short one", textgen.long_line_record(rng, 5000),
+            b"\n".join(textgen.record(rng) for _ in range(800))]
+    for cfg in [(True, 0.35, True, 1024, (64, 256), 512), (False, 0.35, True, 100, (99, 0), 7)]:
+        exp, got = _run(T, ctx, recs, cfg)
+        assert_same(exp, got, recs, "long")
+
+
+def test_chunk_text_materialisation(T, ctx):
+    recs = textgen.corpus(5, 200)
+    data, offs = O.pack(recs)
+    den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy(12, [3, 5], 0.35, 4)
+    import torch
+    db = torch.from_numpy(data).cuda()
+    do = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    dres = ctx.preprocess_batch_device(db.data_ptr(), do.data_ptr(), len(recs), len(data), den, st)
+    host = dres.to_host()
+    exp = O.batch(data, offs, O.make_config(True, 0.35, True, 12, (3, 5), 4))
+    assert_same(exp, host, recs, "device")
+    tptr, optr, nbytes = ctx.materialize_chunk_text()
+    toff = np.empty(host.n_chunks + 1, dtype=np.uint64)
+    text = np.empty(nbytes, dtype=np.uint8)
+    L = T.load_library()
+    assert L.trp_copy_to_host(ctx._h, toff.ctypes.data, optr, toff.nbytes) == 0
+    if nbytes:
+        assert L.trp_copy_to_host(ctx._h, text.ctypes.data, tptr, text.nbytes) == 0
+    for c in range(host.n_chunks):
+        assert text[int(toff[c]):int(toff[c + 1])].tobytes() == exp.chunk_text(c), c
