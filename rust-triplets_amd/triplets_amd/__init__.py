@@ -69,6 +69,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (same SONAME).  Two HIP runtimes in one process cannot both
+    # drive the GPU, so when torch is installed it is imported first and the library binds to the
+    # runtime torch loaded; without torch the system runtime under /opt/rocm is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise TripletsAmdError("HIP library not built: %s is missing (run __graft_entry__.build())"
                                % LIB_PATH)
