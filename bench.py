@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the denoise -> tokenise -> chunk path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 by default)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the whole path (all kernels of trp_preprocess_batch_device) over one packed
+batch that is already resident in HBM.  Workload at every N: BASELINE.json configs[1] - 1.0e9 bytes of
+synthetic ASCII English, records of 3072-5120 bytes, denoiser enabled, default chunking - per GPU
+(weak scaling: records shard by range, no inter-GPU traffic in the timed region).  Rank 0 prints one
+JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rust-triplets_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "corpusgen"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+# Algorithmic HBM bytes of each kernel per launch, as a function of the batch figures: what the kernel
+# has to read and write once given its role (N input bytes, D denoised bytes, T tokens, C chunks,
+# R records, P = N/2 bytes of plan bit planes).
+KERNEL_BYTES = {
+    "k_summary": lambda s: s["N"],
+    "k_plan": lambda s: s["N"] + s["N"] // 2,
+    "k_gate3": lambda s: s["N"] // 8,
+    "k_count_tokens": lambda s: s["N"],
+    "k_emit": lambda s: s["N"] + (s["N"] // 2 if s["enabled"] else 0) + (s["D"] if s["enabled"] else 0)
+    + 8 * s["T"] + 16 * (s["R"] + 1),
+}
+
+
+def path_algorithmic_bytes(s):
+    """B_alg of the whole path: input read once, denoised bytes, token table, chunk descriptors, the
+    four u64 offset arrays and the dropped flags."""
+    return s["N"] + (s["D"] if s["enabled"] else 0) + 8 * s["T"] + 32 * s["C"] + 32 * (s["R"] + 1) + s["R"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bytes", type=int, default=1_000_000_000, help="bytes per GPU")
+    ap.add_argument("--config", default="B", choices=["B", "C", "D"])
+    ap.add_argument("--no-denoise", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import corpusgen
+    import triplets_amd as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic batch for this rank (shard = its own record range of the corpus) -----------------
+    threads = max(1, 16 // max(1, world))
+    seed = {"B": 42, "C": 43, "D": 44}[args.config] + 1000 * rank
+    t0 = time.time()
+    if args.config == "B":
+        data, offs = corpusgen.config_b(args.bytes, seed, threads)
+        workload = "config B: %.1e B synthetic ASCII English, records 3072-5120 B" % args.bytes
+    elif args.config == "C":
+        data, offs = corpusgen.config_c(args.bytes, seed, threads)
+        workload = "config C: %.1e B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB" % args.bytes
+    else:
+        data, offs = corpusgen.config_d(args.bytes, seed, threads)
+        workload = "config D: %.1e B skewed lengths, half the bytes in 200 B and half in 1 MiB records" % args.bytes
+    gen_s = time.time() - t0
+    N, R = int(len(data)), int(len(offs) - 1)
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+
+    den = T.DenoiserConfig(enabled=not args.no_denoise, max_digit_ratio=0.35, strip_markdown=True)
+    st = T.ChunkingStrategy()   # reference defaults: 1024 / [64] / 512
+    ctx = T.Context(local_rank)
+
+    def step():
+        return ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
+
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()                     # returns after the context's stream has drained
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([N], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        total_bytes = float(nn.item())
+    else:
+        total_bytes = float(N)
+
+    stats = {"N": N, "R": R, "D": int(res.n_denoised), "T": int(res.n_tokens), "C": int(res.n_chunks),
+             "enabled": den.enabled}
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_bytes * args.steps / elapsed / 1e9
+
+    # ---- per-kernel durations (HIP events on the launch stream), dominant kernel roofline ----------
+    ctx.set_profiling(True)
+    acc = {}
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        step()
+        for name, ms in ctx.profile():
+            acc[name] = acc.get(name, 0.0) + ms
+    ctx.set_profiling(False)
+    kern = {k: v / reps for k, v in acc.items()}
+    dominant = max(kern, key=kern.get)
+    dom_bytes = KERNEL_BYTES.get(dominant, lambda s: s["N"])(stats)
+    achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms": round(kern[dominant], 4), "algorithmic_bytes": dom_bytes,
+                "path_algorithmic_bytes": path_algorithmic_bytes(stats),
+                "path_frac": round(path_algorithmic_bytes(stats) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            with open(tr) as f:
+                roofline["traffic"] = json.load(f).get(dominant)
+        except Exception:
+            pass
+
+    out = {
+        "metric": "device-resident GB/s of text denoised+tokenised+chunked",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R,
+                   "denoiser": "enabled" if den.enabled else "disabled",
+                   "chunking": "max_window_tokens=1024 overlap=[64] summary_fallback_tokens=512",
+                   "sharding": "record ranges, one shard per GPU, no collective"},
+        "outputs": {"denoised_bytes": stats["D"], "tokens": stats["T"], "chunks": stats["C"]},
+        "roofline": roofline,
+        "corpus_generation_s": round(gen_s, 2),
+    }
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as O
+        cfg = O.make_config(den.enabled, 0.35, True, 1024, (64,), 512)
+        cut = int(np.searchsorted(offs, min(N, 256_000_000), side="right")) - 1
+        cut = max(cut, 1)
+        sub_n = int(offs[cut])
+        L = O.lib()
+        r1 = O.OrcResult()
+        t0 = time.perf_counter()
+        L.orc_batch_mt(data.ctypes.data, offs.ctypes.data, cut, C.byref(cfg), 1, C.byref(r1))
+        t1 = time.perf_counter() - t0
+        L.orc_result_free(C.byref(r1))
+        cores = min(16, os.cpu_count() or 1)
+        r2 = O.OrcResult()
+        t0 = time.perf_counter()
+        L.orc_batch_mt(data.ctypes.data, offs.ctypes.data, R, C.byref(cfg), cores, C.byref(r2))
+        t2 = time.perf_counter() - t0
+        ok = int(r2.n_tokens) == stats["T"] and int(r2.n_denoised) == stats["D"] and int(r2.n_chunks) == stats["C"]
+        L.orc_result_free(C.byref(r2))
+        out["cpu_baseline"] = {"value": round(sub_n / t1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                               "sample": "first %d records (%.0f MB) of the same batch, CPU restatement of the "
+                                         "reference algorithm, 1 thread" % (cut, sub_n / 1e6)}
+        out["cpu_baseline_all_cores"] = {"value": round(N / t2 / 1e9, 4), "unit": "GB/s", "cores": cores,
+                                         "kind": "port", "sample": "whole batch, record-parallel static partition",
+                                         "totals_match_gpu": bool(ok)}
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
