@@ -38,7 +38,24 @@ namespace {
 constexpr int NT = TILE_BLOCKS;   // threads per workgroup
 
 __device__ inline UniTables dev_tables() {
-    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN};
+    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
+    return ut;
+}
+
+// Alphabetic lookups: code points below U+0800 (Latin-1, Greek, Cyrillic, Hebrew, Arabic ...) are
+// served from a 256-byte LDS copy of their eight bitmap rows, the uniform CJK / Hangul ranges by rule
+// (cp_is_alpha_high); only the rest goes to the table in global memory.
+struct UniShared {
+    u32 low[8 * 8];   // bitmap rows of code point blocks 0..7, in block order
+};
+__device__ inline void stage_tables(UniShared& u) {   // needs a barrier before use
+    if (threadIdx.x < 64) {
+        u32 row = trp_alpha_stage1[threadIdx.x >> 3];
+        u.low[threadIdx.x] = trp_alpha_stage2[row * 8 + (threadIdx.x & 7)];
+    }
+}
+__device__ inline UniTables lds_tables(const UniShared& u) {
+    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, u.low};
     return ut;
 }
 
@@ -131,10 +148,28 @@ struct SOp { __device__ S operator()(const S& a, const S& b) const { return s_co
 // ---------------------------------------------------------------------------------------------------
 // tile staging
 // ---------------------------------------------------------------------------------------------------
+// LDS image of a tile: block i of the tile lives at (i + 1) * PAD_STRIDE (64 data bytes + 4 unused, see
+// PadBlk); "block -1" and "block TILE_BLOCKS" hold the 16 halo bytes before / after the tile.
 struct TileShared {
-    alignas(16) u8 bytes[HALO + TILE + HALO];
-    u64 rsw[TILE_BLOCKS + 1];
+    alignas(16) u8 bytes[(TILE_BLOCKS + 2) * PAD_STRIDE];
 };
+
+__device__ inline void lds_store16(u8* dst, uint4 v) {   // dst is 4-byte aligned
+    u32* d = reinterpret_cast<u32*>(dst);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+
+__device__ inline uint4 load16_guarded(const u8* __restrict__ g, u64 N, u64 q) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q + 16 <= N) v = *reinterpret_cast<const uint4*>(g + q);
+    else if (q < N) {
+        u32 w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++)
+            if (q + i < N) w[i >> 2] |= (u32)g[q + i] << (8 * (i & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return v;
+}
 
 // Copy the tile [tS, tS+TILE) plus HALO bytes on both sides into LDS (zeros outside the corpus).
 __device__ inline void stage_tile(const u8* __restrict__ g, u64 N, u64 tS, u8* sb) {
@@ -142,49 +177,29 @@ __device__ inline void stage_tile(const u8* __restrict__ g, u64 N, u64 tS, u8* s
 #pragma unroll
     for (int k = 0; k < TILE / 16 / NT; k++) {
         int c = k * NT + tid;
-        u64 q = tS + (u64)c * 16;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q + 16 <= N) v = *reinterpret_cast<const uint4*>(g + q);
-        else if (q < N) {
-            u8 tmp[16];
-            for (int i = 0; i < 16; i++) tmp[i] = (q + i < N) ? g[q + i] : 0;
-            v = *reinterpret_cast<uint4*>(tmp);
-        }
-        *reinterpret_cast<uint4*>(sb + HALO + c * 16) = v;
+        uint4 v = load16_guarded(g, N, tS + (u64)c * 16);
+        lds_store16(sb + ((c >> 2) + 1) * PAD_STRIDE + (c & 3) * 16, v);
     }
-    if (tid < 2) {
-        u64 q = tid == 0 ? tS - HALO : tS + TILE;
+    if (tid == 0) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        bool ok = tid == 0 ? (tS >= HALO) : true;
-        if (ok && q + 16 <= N) v = *reinterpret_cast<const uint4*>(g + q);
-        else if (ok && q < N) {
-            u8 tmp[16];
-            for (int i = 0; i < 16; i++) tmp[i] = (q + i < N) ? g[q + i] : 0;
-            v = *reinterpret_cast<uint4*>(tmp);
-        }
-        *reinterpret_cast<uint4*>(sb + (tid == 0 ? 0 : HALO + TILE)) = v;
+        if (tS >= HALO) v = load16_guarded(g, N, tS - HALO);
+        lds_store16(sb + 48, v);                                     // last 16 bytes of block -1
+    } else if (tid == 1) {
+        lds_store16(sb + (TILE_BLOCKS + 1) * PAD_STRIDE, load16_guarded(g, N, tS + TILE));
     }
 }
 
-// Record-start bit masks of the tile's blocks; word TILE_BLOCKS bit 0 tells whether the byte right
-// after the tile starts a record.
-__device__ inline void stage_record_starts(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo,
-                                           u64 R, u64 N, u64 t, u64* rsw) {
-    const int tid = threadIdx.x;
-    const u64 tS = t * (u64)TILE;
-    rsw[tid] = 0;
-    if (tid == 0) rsw[TILE_BLOCKS] = 0;
-    __syncthreads();
-    u32 r0 = rec_lo[t], r1 = rec_lo[t + 1];
-    for (u64 r = (u64)r0 + tid; r < r1; r += NT) {
-        u64 p = offsets[r];
-        if (p < N) atomicOr(reinterpret_cast<unsigned long long*>(&rsw[(p - tS) >> 6]), 1ull << ((p - tS) & 63));
-    }
-    if (tid == 0) {
-        u64 tE = tS + TILE;
-        if (tE < N && r1 < R && offsets[r1] == tE) rsw[TILE_BLOCKS] = 1;
-    }
-    __syncthreads();
+__device__ inline PadBlk lane_block(const TileShared& sh, int i) {
+    PadBlk b = {sh.bytes + (i + 1) * PAD_STRIDE};
+    return b;
+}
+
+// k_rsmap: record-start bit map of the corpus (one u64 per 64-byte block, zeroed beforehand).
+__global__ void k_rsmap(const u64* __restrict__ offsets, u64 R, u64 N, u64* __restrict__ rsmap) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    u64 p = offsets[r];
+    if (p < N) atomicOr(reinterpret_cast<unsigned long long*>(&rsmap[p >> 6]), 1ull << (p & 63));
 }
 
 struct LaneCtx {
@@ -195,16 +210,18 @@ struct LaneCtx {
     bool next_rs;   // the byte after the block starts a record or does not exist
 };
 
-__device__ inline LaneCtx lane_setup(const TileShared& sh, u64 N, u64 tS, bool want_lines) {
+// rs_here / rs_next: record-start words of this block and of the next one (rsmap has one spare word).
+__device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, u64 N, u64 tS, bool want_lines,
+                                     u64 rs_here, u64 rs_next) {
     LaneCtx L;
     const int tid = threadIdx.x;
-    const u8* blk = sh.bytes + HALO + tid * BLOCK;
+    const PadBlk blk = lane_block(sh, tid);
     L.p = tS + (u64)tid * BLOCK;
     L.nvalid = L.p >= N ? 0 : (int)((N - L.p) < (u64)BLOCK ? (N - L.p) : (u64)BLOCK);
-    L.c = classify_block(blk, L.nvalid, dev_tables());
+    L.c = classify_block_fast(blk, L.nvalid, ut);
     u64 V = below(L.nvalid);
-    u64 RS = sh.rsw[tid] & V;
-    bool nrs = (sh.rsw[tid + 1] & 1ull) != 0;
+    u64 RS = rs_here & V;
+    bool nrs = (rs_next & 1ull) != 0;
     bool has_next = L.p + BLOCK < N;
     L.next_rs = !has_next || nrs;
     if (want_lines) {
@@ -239,15 +256,18 @@ __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, 
 // ---------------------------------------------------------------------------------------------------
 // k_summary: per-tile forward summary (line statistics at the tile edges, record-level alpha flags).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                                 const u32* __restrict__ rec_lo, u64 R, u64 N,
-                                                 J* __restrict__ SA) {
+__global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
+                                                 u64 nB, J* __restrict__ SA) {
     __shared__ TileShared sh;
+    __shared__ UniShared uni;
     __shared__ J wsum[NT / 64];
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
+    const u64 b = t * (u64)TILE_BLOCKS + threadIdx.x;
     stage_tile(bytes, N, tS, sh.bytes);
-    stage_record_starts(offsets, rec_lo, R, N, t, sh.rsw);
-    LaneCtx L = lane_setup(sh, N, tS, true);
+    stage_tables(uni);
+    const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    __syncthreads();
+    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs_here, rs_next);
     J j = lane_J(L.c, L.d);
     j = wave_reduce_ordered(j, JOp());
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
@@ -304,42 +324,249 @@ __device__ inline S tile_lookahead(const J* __restrict__ SA, u64 t, u64 nT) {
     return acc;
 }
 
-struct PlanShared {
-    TileShared tile;
-    J jscan[NT / 64];
-    S sscan[NT / 64];
-    J seedJ;
-    S seedS;
-    u64 tokc[TILE_BLOCKS];
-    u32 red[2][NT / 64];
+// k_tile_carry: what enters tile t from the left (fold of the summaries back to the start of the
+// record that covers the tile's first byte) and from the right (rest of the line that leaves the tile).
+__global__ __launch_bounds__(NT) void k_tile_carry(const J* __restrict__ SA, u64 nT, J* __restrict__ seedJ,
+                                                    S* __restrict__ seedS) {
+    const u64 t = (u64)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (t >= nT) return;   // whole wave
+    J P = tile_lookback(SA, t);
+    S X = tile_lookahead(SA, t, nT);
+    if ((threadIdx.x & 63) == 0) { seedJ[t] = P; seedS[t] = X; }
+}
+
+// ---- digit-heavy lines solved inside the tile (one wavefront per line) ---------------------------
+constexpr u32 G3_LCAP = 1024;   // lines per tile that can be listed in LDS
+constexpr u32 G3_MAXW = 4;      // a line may touch at most this many 64-byte blocks ...
+constexpr u32 G3_MAXT = 64;     // ... and hold at most this many tokens; longer lines go to k_gate3_solve
+
+struct G3Tok { u32 ts, te, dig, alp; };
+
+// Per-block masks of the tile, kept in the LDS region of the (no longer needed) byte image.
+struct G3Masks {
+    u64 *ws, *pipe, *dig, *alp, *ls;   // inputs
+    u64 *G, *gPSP, *gPNL;              // outputs: kept token bytes, ' ' / '\n' separators
 };
 
-__global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nT,
-                                              const J* __restrict__ SA, DevCfg cfg, Plan* __restrict__ plan,
-                                              u64* __restrict__ g3m, u32* __restrict__ tile_bytes,
-                                              u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
+// Sum of v over the lanes where pred holds, from ballots of the bit planes of v (no cross-lane data
+// movement; v is small here: digits or letters of one token).
+__device__ inline u32 wave_masked_sum(bool pred, u32 v) {
+    u32 sum = 0;
+    for (int bpl = 0; bpl < 32; bpl++) {
+        if (!__ballot(pred && (v >> bpl) != 0)) break;
+        sum += (u32)popc(__ballot(pred && ((v >> bpl) & 1u))) << bpl;
+    }
+    return sum;
+}
+
+// Solves one digit-heavy line (gate 3, reference strip_digit_tokens) with the 64 lanes of a wave: lane
+// t owns token t.  Returns false when the line does not fit (left to the serial kernel).
+// The mask arrays are indexed by block number within a view of n_words blocks; s is the position of
+// the line's first byte in the view and corpus_end the position where the corpus ends (or ~0 when that
+// is outside the view).
+__device__ inline bool g3_wave_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
+                                     float max_ratio, G3Tok* tb, u64* kept_mask_out) {
+    const int lane = threadIdx.x & 63;
+    const u32 w0 = s >> 6;
+    // end of the line: the next line start, or the end of the corpus
+    u32 e = 0xFFFFFFFFu;
+    for (u32 w = w0; w <= w0 + G3_MAXW && w < n_words; w++) {
+        u64 m = a.ls[w];
+        if (w == w0) m &= ~below((int)(s & 63u) + 1);
+        if (m) { e = w * 64u + (u32)ctz(m); break; }
+    }
+    if (e == 0xFFFFFFFFu) {
+        if (corpus_end != 0xFFFFFFFFu && corpus_end <= (w0 + G3_MAXW) * 64u) e = corpus_end;
+        else return false;
+    }
+    const u32 w1 = (e - 1u) >> 6;
+    if (w1 - w0 >= G3_MAXW) return false;
+    const u32 nw = w1 - w0 + 1u;
+    u64 X[G3_MAXW], DG[G3_MAXW], AL[G3_MAXW], TS[G3_MAXW];
+    u32 pre[G3_MAXW + 1];
+    pre[0] = 0;
+    u64 carry = 0;
+#pragma unroll
+    for (u32 j = 0; j < G3_MAXW; j++) {
+        X[j] = DG[j] = AL[j] = TS[j] = 0;
+        if (j < nw) {
+            const u32 w = w0 + j;
+            u64 range = ~0ull;
+            if (w == w0) range &= ~below((int)(s & 63u));
+            if (w == w1 && (e & 63u)) range &= below((int)(e & 63u));
+            const u64 sep = a.ws[w] | (table ? a.pipe[w] : 0ull);
+            X[j] = ~sep & range;
+            DG[j] = a.dig[w] & range;
+            AL[j] = a.alp[w] & range;
+            TS[j] = X[j] & ~((X[j] << 1) | carry);
+            carry = X[j] >> 63;
+        }
+        pre[j + 1] = pre[j] + (u32)popc(TS[j]);
+    }
+    const u32 nt = pre[G3_MAXW];
+    if (nt == 0 || nt > G3_MAXT) return false;
+    // the lane whose index equals the bit position of a token start measures that token
+#pragma unroll
+    for (u32 j = 0; j < G3_MAXW; j++) {
+        if ((TS[j] >> lane) & 1ull) {
+            const u32 t = pre[j] + (u32)popc(TS[j] & below(lane));
+            G3Tok k;
+            k.ts = (w0 + j) * 64u + (u32)lane;
+            const u64 from = ~below(lane);
+            const u64 stop = ~X[j] & from;
+            if (stop) {
+                const int eb = ctz(stop);
+                const u64 r = from & below(eb);
+                k.dig = popc(DG[j] & r);
+                k.alp = popc(AL[j] & r);
+                k.te = (w0 + j) * 64u + (u32)eb;
+            } else {
+                k.dig = popc(DG[j] & from);
+                k.alp = popc(AL[j] & from);
+                k.te = (w0 + nw) * 64u;
+                bool done = false;
+#pragma unroll
+                for (u32 j2 = j + 1; j2 < G3_MAXW; j2++) {
+                    if (!done && j2 < nw) {
+                        const u64 stop2 = ~X[j2];
+                        if (stop2) {
+                            const int eb = ctz(stop2);
+                            k.dig += popc(DG[j2] & below(eb));
+                            k.alp += popc(AL[j2] & below(eb));
+                            k.te = (w0 + j2) * 64u + (u32)eb;
+                            done = true;
+                        } else {
+                            k.dig += popc(DG[j2]);
+                            k.alp += popc(AL[j2]);
+                        }
+                    }
+                }
+            }
+            tb[t] = k;
+        }
+    }
+    __threadfence_block();
+    G3Tok tk = {0, 0, 0, 0};
+    const bool have = (u32)lane < nt;
+    if (have) tk = tb[lane];
+    const bool isalpha = have && tk.alp > 0;
+    const u64 A = __ballot(isalpha);
+    u32 dist = 0xFFFFFFFFu;
+    if (isalpha) dist = 0;
+    else if (have) {
+        const u64 pa = A & below(lane), na = A & ~below(lane + 1);
+        const u32 df = pa ? (u32)(lane - top(pa)) : 0xFFFFFFFFu;
+        const u32 db = na ? (u32)(ctz(na) - lane) : 0xFFFFFFFFu;
+        dist = df < db ? df : db;
+    }
+    u64 d0 = wave_masked_sum(isalpha, tk.dig), a0 = wave_masked_sum(isalpha, tk.alp);
+    u32 K = 0;
+    for (u32 k = 1; k <= G3_MAXT; k++) {
+        const bool in_wave = have && dist == k;
+        if (!__ballot(in_wave)) break;
+        const u64 wd = wave_masked_sum(in_wave, tk.dig);
+        if (ratio_exceeds64(d0 + wd, a0, max_ratio)) break;
+        d0 += wd;
+        K = k;
+    }
+    const bool keep = have && (isalpha || dist <= K);
+    const u64 km = __ballot(keep);
+    if (kept_mask_out) *kept_mask_out = km;
+    if (keep) {
+        const bool first = lane == ctz(km);
+        const u32 ww0 = tk.ts >> 6, ww1 = (tk.te - 1u) >> 6;
+        for (u32 w = ww0; w <= ww1; w++) {
+            const u32 lo_b = w == ww0 ? (tk.ts & 63u) : 0u;
+            const u32 hi_b = w == ww1 ? ((tk.te - 1u) & 63u) + 1u : 64u;
+            atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w]), below((int)hi_b) & ~below((int)lo_b));
+        }
+        const u64 pb = 1ull << (tk.ts & 63u);
+        if (!first) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[ww0]), pb);
+        else if (rab) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[ww0]), pb);
+    }
+    return true;
+}
+
+struct U32Add { __device__ u32 operator()(u32 a, u32 b) const { return a + b; } };
+
+struct PlanShared {
+    TileShared tile;   // byte image; after classification reused for the eight G3Masks arrays
+    J jscan[NT / 64];
+    S sscan[NT / 64];
+    u64 tokc[TILE_BLOCKS];
+    u64 marks[TILE_BLOCKS];
+    uint16_t list[G3_LCAP];
+    G3Tok tok[NT / 64][G3_MAXT];
+    u32 scan32[NT / 64];
+    u32 nlist;
+    u32 red[3][NT / 64];
+};
+static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
+
+__global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N, u64 nB,
+                                              const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
+                                              Plan* __restrict__ plan, u64* __restrict__ g3m,
+                                              u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
+                                              u32* __restrict__ tile_flags, u32* __restrict__ tile_marks) {
     __shared__ PlanShared sh;
+    __shared__ UniShared uni;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
+    const u64 b = t * (u64)TILE_BLOCKS + tid;
     stage_tile(bytes, N, tS, sh.tile.bytes);
-    if (wave == 0) {
-        J P = tile_lookback(SA, t);
-        S X = tile_lookahead(SA, t, nT);
-        if (lane == 0) { sh.seedJ = P; sh.seedS = X; }
-    }
-    stage_record_starts(offsets, rec_lo, R, N, t, sh.tile.rsw);   // contains barriers
-    LaneCtx L = lane_setup(sh.tile, N, tS, true);
+    stage_tables(uni);
+    const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    const J sJ = seedJ[t];
+    const S sS = seedS[t];
+    __syncthreads();
+    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, rs_here, rs_next);
     J j = lane_J(L.c, L.d);
-    J P = block_scan_excl_fwd(j, JOp(), j_identity(), sh.seedJ, sh.jscan, (J*)nullptr);
-    S X = block_scan_excl_bwd(s_from_J(j), SOp(), s_identity(), sh.seedS, sh.sscan);
+    J P = block_scan_excl_fwd(j, JOp(), j_identity(), sJ, sh.jscan, (J*)nullptr);
+    S X = block_scan_excl_bwd(s_from_J(j), SOp(), s_identity(), sS, sh.sscan);
     LaneCarry k = carry_from(P, X, L.next_rs);
     Plan pl = plan_block(L.c, L.d, k, cfg);
-    const u64 b = t * (u64)TILE_BLOCKS + tid;
-    // Lines still to be solved (gate 3) are listed in a plane of their own: k_gate3 finds its work
-    // there while other lanes of that kernel are already writing token bits into the plan.
-    const u64 marks = pl.TOK & ~pl.C;
+    // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
+    // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
+    u64 marks = pl.TOK & ~pl.C;
     pl.TOK &= pl.C;
+    {
+        u64* base = reinterpret_cast<u64*>(sh.tile.bytes);
+        G3Masks gm = {base, base + TILE_BLOCKS, base + 2 * TILE_BLOCKS, base + 3 * TILE_BLOCKS,
+                      base + 4 * TILE_BLOCKS, base + 5 * TILE_BLOCKS, base + 6 * TILE_BLOCKS,
+                      base + 7 * TILE_BLOCKS};
+        // the scans above ended with a barrier: nobody reads the byte image any more
+        gm.ws[tid] = L.c.ws; gm.pipe[tid] = L.c.pipe; gm.dig[tid] = L.c.dig; gm.alp[tid] = L.c.alp;
+        gm.ls[tid] = L.d.LS;
+        gm.G[tid] = 0; gm.gPSP[tid] = 0; gm.gPNL[tid] = 0;
+        sh.marks[tid] = marks;
+        u32 nm = popc(marks), tot = 0;
+        u32 at = block_scan_excl_fwd(nm, U32Add(), 0u, 0u, sh.scan32, &tot);   // ends with a barrier
+        if (tot > 0) {   // uniform
+            for (u64 m = marks; m && at < G3_LCAP; m &= m - 1, at++) {
+                int jb = ctz(m);
+                sh.list[at] = (uint16_t)((u32)(tid * BLOCK + jb) | (((pl.PSP >> jb) & 1ull) ? 0x4000u : 0u) |
+                                    (((pl.PNL >> jb) & 1ull) ? 0x8000u : 0u));
+            }
+            __syncthreads();
+            const u32 nl = tot < G3_LCAP ? tot : G3_LCAP;
+            const u32 tile_valid = (u32)(N - tS < (u64)TILE ? N - tS : (u64)TILE);
+            for (u32 i = wave; i < nl; i += NT / 64) {
+                const u32 ent = sh.list[i], s0 = ent & 0x3FFFu;
+                if (g3_wave_solve(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
+                                  tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, cfg.max_digit_ratio, sh.tok[wave],
+                                  (u64*)nullptr) && lane == 0)
+                    atomicAnd(reinterpret_cast<unsigned long long*>(&sh.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
+            }
+            __syncthreads();
+            const u64 left = sh.marks[tid];
+            const u64 solved = marks & ~left;
+            pl.PSP = (pl.PSP & ~solved) | gm.gPSP[tid];
+            pl.PNL = (pl.PNL & ~solved) | gm.gPNL[tid];
+            pl.C |= gm.G[tid];
+            pl.TOK |= gm.G[tid];
+            marks = left;
+        }
+    }
     if (L.nvalid > 0) { plan[b] = pl; g3m[b] = marks; }
     u64 TOKC = pl.TOK;
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
@@ -347,20 +574,22 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     __syncthreads();
     bool prev_tok = tid > 0 && (sh.tokc[tid - 1] >> 63);
     u64 TS = token_starts(TOKC, L.d.RS, prev_tok);
-    u32 nb = popc(pl.C) + popc(PFX), ntk = popc(TS);
+    u32 nb = popc(pl.C) + popc(PFX), ntk = popc(TS), nmk = popc(marks);
     // workgroup sums
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         nb += __shfl_down((int)nb, off, 64);
         ntk += __shfl_down((int)ntk, off, 64);
+        nmk += __shfl_down((int)nmk, off, 64);
     }
-    if (lane == 0) { sh.red[0][wave] = nb; sh.red[1][wave] = ntk; }
+    if (lane == 0) { sh.red[0][wave] = nb; sh.red[1][wave] = ntk; sh.red[2][wave] = nmk; }
     __syncthreads();
     if (tid == 0) {
-        u32 sb = 0, st = 0;
-        for (int w = 0; w < NT / 64; w++) { sb += sh.red[0][w]; st += sh.red[1][w]; }
+        u32 sb = 0, st = 0, sm = 0;
+        for (int w = 0; w < NT / 64; w++) { sb += sh.red[0][w]; st += sh.red[1][w]; sm += sh.red[2][w]; }
         tile_bytes[t] = sb;
         tile_toks[t] = st;
+        tile_marks[t] = sm;
         u32 f = 0;
         if ((sh.tokc[0] & 1ull) && !(L.d.LS & 1ull)) f |= TF_FIRST_CONT;   // thread 0's own block
         if (sh.tokc[TILE_BLOCKS - 1] >> 63) f |= TF_LAST_TOK;
@@ -369,18 +598,21 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
 }
 
 // Pass-through configuration: token starts per tile (no denoising, the text stays in place).
-__global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                                      const u32* __restrict__ rec_lo, u64 R, u64 N,
-                                                      u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
-                                                      u32* __restrict__ tile_flags) {
+__global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
+                                                      u64 nB, u32* __restrict__ tile_bytes,
+                                                      u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
     __shared__ TileShared sh;
+    __shared__ UniShared uni;
     __shared__ u64 tokc[TILE_BLOCKS];
     __shared__ u32 red[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
+    const u64 b = t * (u64)TILE_BLOCKS + tid;
     stage_tile(bytes, N, tS, sh.bytes);
-    stage_record_starts(offsets, rec_lo, R, N, t, sh.rsw);
-    LaneCtx L = lane_setup(sh, N, tS, false);
+    stage_tables(uni);
+    const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    __syncthreads();
+    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs_here, rs_next);
     Plan pl = plan_passthrough(L.c, L.d.V);
     tokc[tid] = pl.TOK;
     __syncthreads();
@@ -413,57 +645,165 @@ __device__ inline void plan_or(Plan* plan, u64 word, u64 c, u64 tok, u64 psp, u6
     if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PNL), pnl);
 }
 
-__global__ __launch_bounds__(NT) void k_gate3(const u8* __restrict__ bytes, const u64* __restrict__ offsets, u64 R,
-                                               u64 N, u64 nB, DevCfg cfg, Plan* plan,
-                                               const u64* __restrict__ g3m, u32* tile_bytes, u32* tile_toks) {
-    u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nB) return;
-    u64 marks = g3m[b];
-    if (!marks) return;
-    // flag bits at a marked position are only ever changed by the lane that owns the mark
-    u64 pspw = plan[b].PSP, pnlw = plan[b].PNL;
-    UniTables ut = dev_tables();
-    ByteSrc src = {bytes, N};
-    while (marks) {
-        int jb = ctz(marks);
-        marks &= marks - 1;
-        u64 p = b * 64 + jb;
-        bool table = (pspw >> jb) & 1, rab = (pnlw >> jb) & 1;
-        // end of the record that holds p: first offset > p
-        u64 lo = 0, hi = R;
-        while (lo < hi) {
-            u64 mid = (lo + hi) >> 1;
-            if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid;
+// Marked lines -> compact work list (entry = position | table << 32 | rab << 33).  mark_base is the
+// exclusive prefix of the per-tile mark counts.
+__global__ __launch_bounds__(NT) void k_gate3_collect(const u64* __restrict__ g3m, const Plan* __restrict__ plan,
+                                                       u64 nB, const u64* __restrict__ mark_base, u64 cap,
+                                                       u64* __restrict__ list) {
+    __shared__ u32 wsum[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 t = blockIdx.x;
+    const u64 nm = mark_base[t + 1] - mark_base[t];
+    if (nm == 0) return;
+    const u64 b = t * (u64)TILE_BLOCKS + tid;
+    u64 marks = b < nB ? g3m[b] : 0;
+    u32 cnt = popc(marks), inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 o = (u32)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    u32 pre = 0;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    u64 at = mark_base[t] + pre + inc - cnt;
+    if (marks) {
+        // flag bits at a marked position are only ever changed by the lane that solves that line
+        u64 pspw = plan[b].PSP, pnlw = plan[b].PNL;
+        while (marks) {
+            int jb = ctz(marks);
+            marks &= marks - 1;
+            if (at < cap) list[at] = (b * 64 + jb) | (((pspw >> jb) & 1ull) << 32) | (((pnlw >> jb) & 1ull) << 33);
+            at++;
         }
-        u64 rec_end = offsets[lo + 1];
-        u64 e = p;
-        while (e < rec_end) {
-            u8 ch = bytes[e];
-            if (ch == '\n' || ch == '\r') break;
-            e++;
+    }
+}
+
+// Guarded view of a block of the corpus in global memory (zeros outside [0, n)).
+struct GuardBlk {
+    const u8* p;
+    u64 base, n;
+    __device__ u32 operator[](int j) const {
+        long long q = (long long)base + j;
+        return (q >= 0 && (u64)q < n) ? p[q] : 0u;
+    }
+    __device__ u32 word(int k) const {
+        u64 q = base + 4 * (u64)k;
+        if (q + 4 <= n) return *reinterpret_cast<const u32*>(p + q);
+        u32 v = 0;
+        for (int i = 0; i < 4; i++) if (q + i < n) v |= (u32)p[q + i] << (8 * i);
+        return v;
+    }
+};
+
+// Serial solver for one listed line (any length): lane-local walk over the bytes, results OR-ed into
+// the plan with atomics.
+__device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* __restrict__ offsets, u64 R, u64 N,
+                                       const DevCfg& cfg, Plan* plan, u64 p, bool table, bool rab,
+                                       u32* tile_bytes, u32* tile_toks) {
+    const UniTables ut = dev_tables();
+    ByteSrc src = make_src(bytes, N);
+    u64 lo = 0, hi = R;   // end of the record that holds p: first offset > p
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid;
+    }
+    u64 rec_end = offsets[lo + 1];
+    u64 e = p;
+    while (e < rec_end) {
+        u32 ch = src.get(e);
+        if (ch == '\n' || ch == '\r') break;
+        e++;
+    }
+    u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
+    bool first = true;
+    g3_walk(src, p, e, table, ut, K, ~0ull - 1, (u64*)nullptr, (u64*)nullptr,
+            [&](const TokInfo& tk, bool keep) {
+                if (!keep) return;
+                u64 w0 = tk.ts >> 6, w1 = (tk.te - 1) >> 6;
+                for (u64 w = w0; w <= w1; w++) {
+                    u64 lo_b = w == w0 ? (tk.ts & 63) : 0;
+                    u64 hi_b = w == w1 ? ((tk.te - 1) & 63) + 1 : 64;
+                    u64 m = below((int)hi_b) & ~below((int)lo_b);
+                    u64 pre = (w == w0) ? (1ull << lo_b) : 0;
+                    plan_or(plan, w, m, m, (pre && !first) ? pre : 0, (pre && first && rab) ? pre : 0);
+                    atomicAdd(&tile_bytes[w / TILE_BLOCKS], (u32)popc(m));
+                }
+                if (!first || rab) atomicAdd(&tile_bytes[w0 / TILE_BLOCKS], 1u);
+                atomicAdd(&tile_toks[w0 / TILE_BLOCKS], 1u);
+                first = false;
+            });
+}
+
+// Lines that k_plan could not solve inside a tile (they cross a tile edge or are too long): one
+// wavefront per listed line.  Lines of up to G3_MAXW blocks are re-classified from global memory by
+// five lanes and go through the same wave solver; the rest is walked serially by lane 0.
+constexpr u32 G3_VIEW = G3_MAXW + 1;
+__global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
+                                                     const u64* __restrict__ offsets, u64 R, u64 N, u64 nB, DevCfg cfg,
+                                                     Plan* plan, const u64* __restrict__ list,
+                                                     const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
+                                                     u32* tile_toks, u64* __restrict__ totals) {
+    __shared__ u64 masks[NT / 64][8][G3_VIEW + 1];
+    __shared__ G3Tok tok[NT / 64][G3_MAXT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 n = *mark_total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[4] = n; totals[5] = n > cap ? 1 : 0; }
+    if (n > cap) n = cap;
+    const u64 nwaves = (u64)gridDim.x * (NT / 64);
+    for (u64 i = (u64)blockIdx.x * (NT / 64) + wave; i < n; i += nwaves) {
+        const u64 ent = list[i];
+        const u64 p = ent & 0xFFFFFFFFull;
+        const bool table = (ent >> 32) & 1, rab = (ent >> 33) & 1;
+        const u64 w0 = p >> 6;
+        u64(*m)[G3_VIEW + 1] = masks[wave];
+        if (lane < (int)G3_VIEW) {
+            const u64 wb = w0 + lane;
+            Cls c = {0, 0, 0, 0, 0, 0, 0};
+            u64 LS = 0;
+            if (wb < nB) {
+                GuardBlk blk = {bytes, wb * 64, N};
+                const u64 q = wb * 64;
+                const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
+                c = classify_block_fast(blk, nvalid, dev_tables());
+                const u64 V = below(nvalid);
+                const u64 RS = rsmap[wb] & V;
+                const bool nrs = (wb + 1 < nB) && (rsmap[wb + 1] & 1ull);
+                const bool has_next = q + 64 < N;
+                const bool next_nl = has_next && blk[64] == '\n' && !nrs;
+                const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
+                LS = derive(c, V, RS, next_nl, pt).LS;
+            }
+            m[0][lane] = c.ws; m[1][lane] = c.pipe; m[2][lane] = c.dig; m[3][lane] = c.alp; m[4][lane] = LS;
+            m[5][lane] = 0; m[6][lane] = 0; m[7][lane] = 0;
         }
-        u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
-        // clear the marker, then write the kept tokens
-        u64 mb = ~(1ull << jb);
-        atomicAnd(reinterpret_cast<unsigned long long*>(&plan[b].PSP), mb);
-        atomicAnd(reinterpret_cast<unsigned long long*>(&plan[b].PNL), mb);
-        bool first = true;
-        g3_walk(src, p, e, table, ut, K, ~0ull - 1, (u64*)nullptr, (u64*)nullptr,
-                [&](const TokInfo& tk, bool keep) {
-                    if (!keep) return;
-                    u64 w0 = tk.ts >> 6, w1 = (tk.te - 1) >> 6;
-                    for (u64 w = w0; w <= w1; w++) {
-                        u64 lo_b = w == w0 ? (tk.ts & 63) : 0;
-                        u64 hi_b = w == w1 ? ((tk.te - 1) & 63) + 1 : 64;
-                        u64 m = below((int)hi_b) & ~below((int)lo_b);
-                        u64 pre = (w == w0) ? (1ull << lo_b) : 0;
-                        plan_or(plan, w, m, m, (pre && !first) ? pre : 0, (pre && first && rab) ? pre : 0);
-                        atomicAdd(&tile_bytes[w / TILE_BLOCKS], (u32)popc(m));
-                    }
-                    if (!first || rab) atomicAdd(&tile_bytes[w0 / TILE_BLOCKS], 1u);
-                    atomicAdd(&tile_toks[w0 / TILE_BLOCKS], 1u);
-                    first = false;
-                });
+        __threadfence_block();
+        G3Masks gm = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]};
+        const u64 view0 = w0 * 64;
+        const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
+        u64 km = 0;
+        const bool ok = g3_wave_solve(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio, tok[wave], &km);
+        __threadfence_block();
+        const u64 mb = ~(1ull << (p & 63));
+        if (lane == 0) {   // the marker's flag bits
+            atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PSP), mb);
+            atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PNL), mb);
+        }
+        if (ok) {
+            if (lane < (int)G3_VIEW && m[5][lane]) {
+                const u64 wb = w0 + lane;
+                const u64 g = m[5][lane], sp = m[6][lane], nl = m[7][lane];
+                plan_or(plan, wb, g, g, sp, nl);
+                atomicAdd(&tile_bytes[wb / TILE_BLOCKS], (u32)(popc(g) + popc(sp | nl)));
+                // token starts of this block: kept bytes whose predecessor is not kept
+                const u64 prevg = lane > 0 ? m[5][lane - 1] >> 63 : 0;
+                atomicAdd(&tile_toks[wb / TILE_BLOCKS], (u32)popc(g & ~((g << 1) | prevg)));
+            }
+        } else if (lane == 0) {
+            g3_serial_solve(bytes, offsets, R, N, cfg, plan, p, table, rab, tile_bytes, tile_toks);
+        }
+        __threadfence_block();
     }
 }
 
@@ -542,6 +882,11 @@ __global__ __launch_bounds__(NT) void k_scan_final(const u64* __restrict__ in, u
 
 // tile counts -> packed u64 (bytes | toks << 32); a token that continues across a tile edge was
 // counted as a start by the right-hand tile: take it back here.
+__global__ void k_widen_u32(const u32* __restrict__ in, u64 n, u64* __restrict__ out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
 __global__ void k_pack_tiles(const u32* __restrict__ tile_bytes, const u32* __restrict__ tile_toks,
                              const u32* __restrict__ tile_flags, u64 nT, u64* __restrict__ packed) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,14 +900,16 @@ __global__ void k_pack_tiles(const u32* __restrict__ tile_bytes, const u32* __re
 // k_emit: stream compaction of the tile per its plan -> denoised bytes, token table, per-record offsets
 // ---------------------------------------------------------------------------------------------------
 struct EmitScan {
-    u32 nb, ntk;
-    int lts;   // tile-relative byte position of the last token start so far, -1 none
+    u32 nb, ntk, nte;   // emitted bytes, token starts, token ends
+    int lts;            // tile-relative byte position of the last token start so far, -1 none
 };
+constexpr u32 TOK_CAP = 4096;   // tokens per tile staged in LDS (16 KiB); the rest is stored directly
 struct EmitOp {
     __device__ EmitScan operator()(const EmitScan& a, const EmitScan& b) const {
         EmitScan r;
         r.nb = a.nb + b.nb;
         r.ntk = a.ntk + b.ntk;
+        r.nte = a.nte + b.nte;
         r.lts = b.lts >= 0 ? b.lts : a.lts;
         return r;
     }
@@ -570,14 +917,14 @@ struct EmitOp {
 
 struct EmitShared {
     TileShared tile;
-    alignas(16) u8 out[TILE + 48];
-    u64 tokc[TILE_BLOCKS + 1];
+    alignas(16) u8 out[TILE + 64];   // output image of the tile (linear)
+    u64 tokc[TILE_BLOCKS];
     u64 cw[TILE_BLOCKS], pfx[TILE_BLOCKS], ts[TILE_BLOCKS];
     u32 eb[TILE_BLOCKS], tb[TILE_BLOCKS];
     EmitScan scan[NT / 64];
     EmitScan total;
     u64 cin_start;      // corpus position where the token that runs into this tile starts
-    u32 flags;          // bit0: byte before the tile is a token byte of the same record, bit1: byte after is
+    u32 flags;          // bit0: the tile's first byte continues a token that started before the tile
 };
 
 // Position where the token covering byte tS-1 starts (the tile's first byte continues it).
@@ -593,7 +940,8 @@ __device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 
                 long long a = (long long)c + i;
                 w[i + 3] = (a >= 0 && (u64)a < N) ? bytes[a] : 0;
             }
-            if (byte_is_ws(w + 3)) break;
+            PlainBlk wb = {w};
+            if (byte_is_ws(wb, 3)) break;
             q--;
         }
         return q;
@@ -613,66 +961,63 @@ __device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 
 }
 
 template <bool PASSTHROUGH>
-__global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nT,
-                                              const Plan* __restrict__ plan, const u64* __restrict__ tile_base,
-                                              u8* __restrict__ denoised, u32* __restrict__ tok_start,
-                                              u32* __restrict__ tok_len, u64* __restrict__ den_off,
-                                              u64* __restrict__ tok_off) {
+__global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
+                                              const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
+                                              u64 N, u64 nB, const Plan* __restrict__ plan,
+                                              const u64* __restrict__ tile_base, u8* __restrict__ denoised,
+                                              u32* __restrict__ tok_start, u32* __restrict__ tok_len,
+                                              u64* __restrict__ den_off, u64* __restrict__ tok_off) {
     __shared__ EmitShared sh;
     const int tid = threadIdx.x;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
     const u64 b = t * (u64)TILE_BLOCKS + tid;
     stage_tile(bytes, N, tS, sh.tile.bytes);
-    stage_record_starts(offsets, rec_lo, R, N, t, sh.tile.rsw);
-    const u8* blk = sh.tile.bytes + HALO + tid * BLOCK;
+    const PadBlk blk = lane_block(sh.tile, tid);
     const u64 p = tS + (u64)tid * BLOCK;
     const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)BLOCK ? (N - p) : (u64)BLOCK);
     const u64 V = below(nvalid);
-    const u64 RS = sh.tile.rsw[tid] & V;
-    const bool next_rs = !(p + BLOCK < N) || (sh.tile.rsw[tid + 1] & 1ull);
+    const u64 RS = (b < nB ? rsmap[b] : 0) & V;
+    const bool next_rs = !(p + BLOCK < N) || (rsmap[b + 1] & 1ull);
     Plan pl = {0, 0, 0, 0};
+    if (!PASSTHROUGH && nvalid > 0) pl = plan[b];
+    // neighbours across the tile edges are fetched by the first and the last lane along with their
+    // own words, so that no lane waits for a memory round trip of its own later
+    u64 prev_w = 0, prev_rs = 0;   // lane 0: token bytes / record starts of the block before the tile
+    bool edge_prev = false, edge_next = false;
+    if (tid == 0 && b > 0) {
+        prev_rs = rsmap[b - 1];
+        if (!PASSTHROUGH) prev_w = plan[b - 1].TOK & plan[b - 1].C;
+    }
+    if (!PASSTHROUGH && tid == NT - 1 && b + 1 < nB) edge_next = (plan[b + 1].TOK & plan[b + 1].C) & 1ull;
+    __syncthreads();
     if (PASSTHROUGH) {
-        Cls c = classify_block(blk, nvalid, dev_tables());
+        Cls c = classify_block_fast(blk, nvalid, dev_tables());
         pl = plan_passthrough(c, V);
-    } else if (nvalid > 0) {
-        pl = plan[b];
+        if (tid == 0 && b > 0) edge_prev = !byte_is_ws(blk, -1);
+        if (tid == NT - 1 && p + BLOCK < N) edge_next = !byte_is_ws(blk, BLOCK);
+    } else if (tid == 0) {
+        edge_prev = (prev_w >> 63) != 0;
     }
     const u64 TOKC = pl.TOK & pl.C;
     const u64 PFX = (pl.PSP | pl.PNL) & pl.C;
     sh.tokc[tid] = TOKC;
-    if (tid == 0) {
-        // neighbours across the tile edges
-        u32 f = 0;
-        if (tS > 0) {
-            bool pt = PASSTHROUGH ? !byte_is_ws(blk - 1) : (((plan[b - 1].TOK & plan[b - 1].C) >> 63) & 1);
-            if (pt) f |= 1;
-        }
-        u64 tE = tS + TILE;
-        if (tE < N) {
-            bool nt = PASSTHROUGH ? !byte_is_ws(sh.tile.bytes + HALO + TILE)
-                                  : ((plan[b + TILE_BLOCKS].TOK & plan[b + TILE_BLOCKS].C) & 1);
-            if (nt) f |= 2;
-        }
-        sh.flags = f;
-    }
     __syncthreads();
-    if (tid == 0) sh.tokc[TILE_BLOCKS] = (sh.flags & 2) ? 1 : 0;
-    const bool prev_tok = tid > 0 ? (sh.tokc[tid - 1] >> 63) != 0 : (sh.flags & 1) != 0;
-    __syncthreads();
-    const bool next_tok = (sh.tokc[tid + 1] & 1ull) != 0;
+    const bool prev_tok = tid > 0 ? (sh.tokc[tid - 1] >> 63) != 0 : edge_prev;
+    const bool next_tok = tid < NT - 1 ? (sh.tokc[tid + 1] & 1ull) != 0 : edge_next;
     const u64 TS = token_starts(TOKC, RS, prev_tok);
     const u64 TE = token_ends(TOKC, RS, next_tok, next_rs);
     EmitScan me;
     me.nb = popc(pl.C) + popc(PFX);
     me.ntk = popc(TS);
+    me.nte = popc(TE);
     me.lts = TS ? tid * BLOCK + top(TS) : -1;
-    EmitScan ident = {0, 0, -1};
+    EmitScan ident = {0, 0, 0, -1};
     const u64 tb64 = tile_base[t];
-    EmitScan seed = {(u32)(tb64 & 0xFFFFFFFFull), (u32)(tb64 >> 32), -1};
+    EmitScan seed = {(u32)(tb64 & 0xFFFFFFFFull), (u32)(tb64 >> 32), 0, -1};
     EmitScan tot;
     EmitScan ex = block_scan_excl_fwd(me, EmitOp(), ident, seed, sh.scan, &tot);
-    const u32 out0 = seed.nb;                 // first output byte of this tile
+    const u32 out0 = PASSTHROUGH ? (u32)tS : seed.nb;   // output position of the tile's first byte
+    const u32 tok0 = seed.ntk;                           // index of the first token that starts in the tile
     const u32 shift = PASSTHROUGH ? 0 : (out0 & 15u);
     sh.cw[tid] = pl.C;
     sh.pfx[tid] = PFX;
@@ -681,43 +1026,109 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     sh.tb[tid] = ex.ntk;
     if (tid == 0) {
         sh.total = tot;
-        // does a token run into this tile from the left?
+        // does a token run into this tile from the left?  Find where it starts.
         sh.cin_start = 0;
+        sh.flags = 0;
         if ((TOKC & 1ull) && prev_tok && !(RS & 1ull)) {
-            u32 r0 = rec_lo[t];   // first record starting at/after tS; the covering record is r0-1
-            u64 rec_start = r0 > 0 ? offsets[r0 - 1] : 0;
-            sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, rec_start);
+            sh.flags = 1;
+            long long at = -1;   // start position inside the previous block, if it can be told from there
+            if (PASSTHROUGH) {
+                for (int k = 1; k <= 12; k++) {
+                    if ((prev_rs >> (64 - k)) & 1ull) { at = 64 - k; break; }
+                    if (byte_is_ws(blk, -k - 1)) { at = 64 - k; break; }
+                }
+            } else {
+                u64 zeros = ~prev_w;   // bit 63 of prev_w is set
+                long long z = zeros ? top(zeros) + 1 : -1, r = prev_rs ? top(prev_rs) : -1;
+                at = z > r ? z : r;
+            }
+            if (at >= 0) sh.cin_start = (b - 1) * 64 + (u64)at;
+            else {
+                u32 r0 = rec_lo[t];   // first record starting at/after tS; the covering record is r0-1
+                u64 rec_start = r0 > 0 ? offsets[r0 - 1] : 0;
+                sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, rec_start);
+            }
         }
     }
-    // bytes -> LDS output image
+    // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes
+    // with no separator inside; its source is contiguous in the lane's block and its destination is
+    // contiguous in the output image, so it moves as (unaligned source, aligned destination) dwords.
+    // Lanes start their runs at different dwords so that the stride-64 pattern spreads over the banks.
     if (!PASSTHROUGH) {
-        u32 pos = ex.nb - out0 + shift;
-        u64 c = pl.C;
-        while (c) {
-            int j = ctz(c);
-            c &= c - 1;
-            if ((PFX >> j) & 1) sh.out[pos++] = ((pl.PNL >> j) & 1) ? '\n' : ' ';
-            sh.out[pos++] = blk[j];
+        typedef u32 __attribute__((aligned(1))) u32u;
+        const u8* src0 = blk.p;
+        u32 o = ex.nb - out0 + shift;
+        u64 Cm = pl.C;
+        u64 brk = Cm & (PFX | ~(Cm << 1));
+        const u32 lrot = threadIdx.x & 15;
+        while (brk) {
+            int a0 = ctz(brk);
+            brk &= brk - 1;
+            u64 rest = ~Cm >> a0;
+            u32 len = rest ? (u32)ctz(rest) : (u32)(64 - a0);
+            if (brk) { u32 nb = (u32)ctz(brk) - (u32)a0; if (nb < len) len = nb; }
+            if ((PFX >> a0) & 1) { sh.out[o] = ((pl.PNL >> a0) & 1) ? '\n' : ' '; o++; }
+            const u8* src = src0 + a0;
+            u8* dst = sh.out + o;
+            u32 head = (4u - (o & 3u)) & 3u;
+            if (head > len) head = len;
+            for (u32 i = 0; i < head; i++) dst[i] = src[i];
+            const u32 nd = (len - head) >> 2;
+            const u32 rot = (lrot * nd) >> 4;
+            for (u32 q = 0; q < nd; q++) {
+                u32 k = q + rot;
+                if (k >= nd) k -= nd;
+                *reinterpret_cast<u32*>(dst + head + 4 * k) = *reinterpret_cast<const u32u*>(src + head + 4 * k);
+            }
+            for (u32 i = head + 4 * nd; i < len; i++) dst[i] = src[i];
+            o += len;
         }
     }
     __syncthreads();
-    // tokens: one record per token end
+    // tokens: one (start, len) record per token end.  Tokens that start and end inside the tile are
+    // staged in LDS (the input image is no longer needed) and stored with coalesced writes below.
+    u32* tokstage = reinterpret_cast<u32*>(sh.tile.bytes);
     {
-        u64 te = TE;
-        while (te) {
-            int x = ctz(te);
+        const bool plain = PASSTHROUGH || (pl.C == V && PFX == 0);   // output position = ex.nb + bit index
+        auto outpos = [&](int j) -> u32 {   // output position of the (copied) byte at bit j
+            if (PASSTHROUGH) return (u32)p + (u32)j;
+            if (plain) return ex.nb + (u32)j;
+            return ex.nb + popc(pl.C & below(j)) + popc(PFX & below(j + 1));
+        };
+        auto put = [&](u32 idx, u32 start_out, u32 len, bool inside) {
+            if (inside && idx - tok0 < TOK_CAP) tokstage[idx - tok0] = (start_out - out0) | (len << 16);
+            else { tok_start[idx] = start_out; tok_len[idx] = len; }
+        };
+        u64 ts = TS, te = TE;
+        u32 idx = ex.ntk;   // index of the next token that starts in this block
+        if (te) {
+            int x0 = ctz(te);
+            if (!ts || x0 < ctz(ts)) {
+                // the token that runs into this block from the left ends at x0
+                bool inside = ex.lts >= 0;
+                u64 start_abs = inside ? tS + (u64)ex.lts : sh.cin_start;
+                u32 len = (u32)(p + x0 - start_abs + 1);
+                put(idx - 1, outpos(x0) - (len - 1), len, inside);
+                te &= te - 1;
+            }
+        }
+        while (te) {   // from here on starts and ends alternate
+            int s0 = ctz(ts), x = ctz(te);
+            ts &= ts - 1;
             te &= te - 1;
-            u64 sb = TS & below(x + 1);
-            u64 start_abs;   // corpus position of the token's first byte
-            if (sb) start_abs = p + top(sb);
-            else start_abs = ex.lts >= 0 ? tS + (u64)ex.lts : sh.cin_start;
-            u64 end_abs = p + x;
-            u32 idx = ex.ntk + popc(sb) - 1;
-            u32 out_end = PASSTHROUGH ? (u32)end_abs
-                                      : ex.nb + popc(pl.C & below(x)) + popc(PFX & below(x + 1));
-            u32 len = (u32)(end_abs - start_abs + 1);
-            tok_start[idx] = out_end - (len - 1);
-            tok_len[idx] = len;
+            put(idx, outpos(s0), (u32)(x - s0 + 1), true);
+            idx++;
+        }
+    }
+    __syncthreads();
+    {
+        const bool starts_inside_token = (sh.flags & 1) != 0;
+        u32 n_ss = sh.total.nte - ((starts_inside_token && sh.total.nte > 0) ? 1u : 0u);
+        if (n_ss > TOK_CAP) n_ss = TOK_CAP;
+        for (u32 i = tid; i < n_ss; i += NT) {
+            u32 v = tokstage[i];
+            tok_start[tok0 + i] = out0 + (v & 0xFFFFu);
+            tok_len[tok0 + i] = v >> 16;
         }
     }
     // per-record offsets
@@ -739,10 +1150,11 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
         const u32 end = shift + n;
         for (u32 c16 = tid; c16 * 16 < end; c16 += NT) {
             u32 lo = c16 * 16, hi = lo + 16;
+            const u8* src = sh.out + lo;
             if (lo >= shift && hi <= end) {
-                *reinterpret_cast<uint4*>(denoised + g0 + lo) = *reinterpret_cast<const uint4*>(sh.out + lo);
+                *reinterpret_cast<uint4*>(denoised + g0 + lo) = *reinterpret_cast<const uint4*>(src);
             } else {
-                for (u32 i = lo > shift ? lo : shift; i < hi && i < end; i++) denoised[g0 + i] = sh.out[i];
+                for (u32 i = lo > shift ? lo : shift; i < hi && i < end; i++) denoised[g0 + i] = src[i - lo];
             }
         }
     }
@@ -891,7 +1303,7 @@ struct DevBuf {
 struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf rec_lo, SA, plan, g3m, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
+    DevBuf rec_lo, rsmap, SA, seedJ, seedS, plan, g3m, tile_marks, marks64, mark_base, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
@@ -996,7 +1408,8 @@ void trp_destroy(trp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->rec_lo, &c->SA, &c->plan, &c->g3m, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
+    DevBuf* bufs[] = {&c->rec_lo, &c->rsmap, &c->SA, &c->seedJ, &c->seedS, &c->plan, &c->g3m, &c->tile_marks,
+                      &c->marks64, &c->mark_base, &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
                       &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len};
@@ -1041,7 +1454,12 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
     if (chunk_cap > chunk_cap_limit) chunk_cap = chunk_cap_limit;
     if (c->chunks.cap / sizeof(ChunkDesc) > chunk_cap) chunk_cap = c->chunks.cap / sizeof(ChunkDesc);
 
+    // list of digit-heavy lines: sized for one line per 256 bytes; a batch that needs more is run again
+    // with the exact size (the context keeps the larger buffer)
+    u64 g3_cap = N / 256 + 4096;
+    if (c->g3list.cap / sizeof(u64) > g3_cap) g3_cap = c->g3list.cap / sizeof(u64);
     if ((rc = c->rec_lo.ensure((nT + 2) * sizeof(u32)))) return rc;
+    if ((rc = c->rsmap.ensure((nB + 2) * sizeof(u64)))) return rc;
     if ((rc = c->tile_bytes.ensure((nT + 1) * sizeof(u32)))) return rc;
     if ((rc = c->tile_toks.ensure((nT + 1) * sizeof(u32)))) return rc;
     if ((rc = c->tile_flags.ensure((nT + 1) * sizeof(u32)))) return rc;
@@ -1061,6 +1479,12 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
         if ((rc = c->plan.ensure((nB + 1) * sizeof(Plan)))) return rc;
         if ((rc = c->g3m.ensure((nB + 1) * sizeof(u64)))) return rc;
         if ((rc = c->denoised.ensure(N + 64))) return rc;
+        if ((rc = c->seedJ.ensure((nT + 1) * sizeof(J)))) return rc;
+        if ((rc = c->seedS.ensure((nT + 1) * sizeof(S)))) return rc;
+        if ((rc = c->tile_marks.ensure((nT + 1) * sizeof(u32)))) return rc;
+        if ((rc = c->marks64.ensure((nT + 1) * sizeof(u64)))) return rc;
+        if ((rc = c->mark_base.ensure((nT + 2) * sizeof(u64)))) return rc;
+        if ((rc = c->g3list.ensure(g3_cap * sizeof(u64)))) return rc;
     }
     hipStream_t st = c->stream;
     u32* rec_lo = c->rec_lo.as<u32>();
@@ -1071,25 +1495,38 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
     Plan* plan = c->plan.as<Plan>();
     J* SA = c->SA.as<J>();
     c->events.clear();
+    HIPCHK(hipMemsetAsync(totals, 0, 8 * sizeof(u64), st));
 
+    u64* rsmap = c->rsmap.as<u64>();
     {
-        Prof pr(c, "k_rec_lo");
+        Prof pr(c, "k_rec_lo+rsmap");
         hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + 2 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, rec_lo);
+        HIPCHK(hipMemsetAsync(rsmap, 0, (nB + 2) * sizeof(u64), st));
+        if (R) hipLaunchKernelGGL(k_rsmap, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, rsmap);
     }
     if (nT) {
         if (!pass) {
             { Prof pr(c, "k_summary");
-              hipLaunchKernelGGL(k_summary, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, SA); }
+              hipLaunchKernelGGL(k_summary, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, SA); }
+            { Prof pr(c, "k_tile_carry");
+              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)((nT + NT / 64 - 1) / (NT / 64))), dim3(NT), 0, st, SA, nT,
+                                 c->seedJ.as<J>(), c->seedS.as<S>()); }
             { Prof pr(c, "k_plan");
-              hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nT, SA, dc,
-                                 plan, c->g3m.as<u64>(), tbytes, ttoks, tflags); }
+              hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, c->seedJ.as<J>(),
+                                 c->seedS.as<S>(), dc, plan, c->g3m.as<u64>(), tbytes, ttoks, tflags,
+                                 c->tile_marks.as<u32>()); }
             { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_gate3, dim3((unsigned)((nB + NT - 1) / NT)), dim3(NT), 0, st, d_bytes, d_offsets, R, N, nB,
-                                 dc, plan, c->g3m.as<u64>(), tbytes, ttoks); }
+              hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, c->tile_marks.as<u32>(), nT,
+                                 c->marks64.as<u64>());
+              if ((rc = scan_u64(c, c->marks64.as<u64>(), nT, c->mark_base.as<u64>()))) return rc;
+              hipLaunchKernelGGL(k_gate3_collect, dim3((unsigned)nT), dim3(NT), 0, st, c->g3m.as<u64>(), plan, nB,
+                                 c->mark_base.as<u64>(), g3_cap, c->g3list.as<u64>());
+              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, R, N, nB, dc, plan,
+                                 c->g3list.as<u64>(), c->mark_base.as<u64>() + nT, g3_cap, tbytes, ttoks, totals); }
         } else {
             Prof pr(c, "k_count_tokens");
-            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, tbytes,
-                               ttoks, tflags);
+            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, tbytes, ttoks,
+                               tflags);
         }
         { Prof pr(c, "scan_tiles");
           hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, tbytes, ttoks, tflags, nT,
@@ -1097,11 +1534,11 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
           if ((rc = scan_u64(c, c->packed.as<u64>(), nT, tile_base))) return rc; }
         { Prof pr(c, "k_emit");
           if (pass)
-              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nT,
+              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, rec_lo, R, N, nB,
                                  (const Plan*)nullptr, tile_base, (u8*)nullptr, c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off);
           else
-              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nT,
+              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, rec_lo, R, N, nB,
                                  plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off); }
     }
@@ -1118,8 +1555,14 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
       hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, chunk_cap,
                          c->chunks.as<ChunkDesc>(), totals); }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_totals, totals, 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_totals, totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (!pass && nT && c->h_totals[5]) {
+        // more digit-heavy lines than the work list holds: grow it to the exact size and run the batch again
+        if (c->h_totals[4] <= g3_cap) return fail(TRP_E_HIP, "inconsistent gate-3 list size");
+        if ((rc = c->g3list.ensure(c->h_totals[4] * sizeof(u64)))) return rc;
+        return trp_preprocess_batch_device(c, d_bytes, d_offsets, R, N, cfg, out);
+    }
     if (c->h_totals[3]) {
         // the optimistic descriptor buffer was too small: grow to the exact size and emit again
         chunk_cap = c->h_totals[2];

@@ -56,32 +56,57 @@ TRP_HD bool cp_is_ws_high(u32 cp) {
            cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
 }
 
-// Unicode Alphabetic (char::is_alphabetic) through the generated two-stage table.
-TRP_HD bool cp_is_alpha_high(u32 cp, const u8* stage1, const u32* stage2, u32 stage1_len) {
-    u32 blk = cp >> 8;
-    if (blk >= stage1_len) return false;
-    u32 row = stage1[blk];
-    u32 o = cp & 255u;
-    return (stage2[row * 8 + (o >> 5)] >> (o & 31u)) & 1u;
-}
-
 struct UniTables {
     const u8* stage1;
     const u32* stage2;
     u32 stage1_len;
+    const u32* low8;   // optional: the bitmap rows of code point blocks 0..7 in block order (64 words)
 };
 
-// Decode the multi-byte sequence whose lead byte is at q[0] (q[0] >= 0xC0).  q[1..3] must be
+// Unicode Alphabetic (char::is_alphabetic) through the generated two-stage table.  The big uniform
+// ranges (CJK ideographs, Hangul syllables: every code point Alphabetic) are answered without a
+// table access; tests check this shortcut against the table for every code point.
+TRP_HD bool cp_is_alpha_high(u32 cp, const UniTables& ut) {
+    if ((cp >= 0x3400 && cp <= 0x4DBF) || (cp >= 0x4E00 && cp <= 0x9FFF) || (cp >= 0xAC00 && cp <= 0xD7A3))
+        return true;
+    u32 blk = cp >> 8;
+    u32 o = cp & 255u;
+    if (ut.low8 && blk < 8) return (ut.low8[blk * 8 + (o >> 5)] >> (o & 31u)) & 1u;
+    if (blk >= ut.stage1_len) return false;
+    u32 row = ut.stage1[blk];
+    return (ut.stage2[row * 8 + (o >> 5)] >> (o & 31u)) & 1u;
+}
+
+// Block accessors.  A block is 64 bytes with at least 4 readable bytes before and after it (indices
+// -4..67).  PlainBlk: the bytes are contiguous in memory.  PadBlk: the staged LDS image, where every
+// 64-byte block is followed by 4 unused bytes so that lanes that touch the same byte index of their
+// blocks fall into different LDS banks (block stride 68 bytes = 17 banks).
+struct PlainBlk {
+    const u8* p;
+    TRP_HD u32 operator[](int j) const { return p[j]; }
+    TRP_HD u32 word(int k) const {
+        return (u32)p[4 * k] | ((u32)p[4 * k + 1] << 8) | ((u32)p[4 * k + 2] << 16) | ((u32)p[4 * k + 3] << 24);
+    }
+};
+constexpr int PAD_STRIDE = 68;
+struct PadBlk {
+    const u8* p;
+    TRP_HD u32 operator[](int j) const { return p[j + 4 * (j >> 6)]; }
+    TRP_HD u32 word(int k) const { return *reinterpret_cast<const u32*>(p + 4 * k); }
+};
+
+// Decode the multi-byte sequence whose lead byte is q[at] (>= 0xC0).  q[at+1..at+3] must be
 // readable.  Returns the sequence length (2..4) and the scalar value, or 0 when malformed.
-TRP_HD int decode_lead(const u8* q, u32* cp) {
-    u32 b0 = q[0];
+template <class B>
+TRP_HD int decode_lead(const B& q, int at, u32* cp) {
+    u32 b0 = q[at];
     int n;
     u32 v;
     if (b0 < 0xE0) { n = 2; v = b0 & 0x1F; }
     else if (b0 < 0xF0) { n = 3; v = b0 & 0x0F; }
     else { n = 4; v = b0 & 0x07; }
     for (int i = 1; i < n; i++) {
-        u32 c = q[i];
+        u32 c = q[at + i];
         if ((c & 0xC0) != 0x80) return 0;
         v = (v << 6) | (c & 0x3F);
     }
@@ -111,17 +136,20 @@ TRP_HD u64 brev(u64 x) {
 // ---- per-block class masks -----------------------------------------------------------------------
 struct Cls {
     u64 ws, nl, cr, pipe, dig, alp;
+    u64 sp;   // the byte is exactly 0x20
 };
 
 // Classify `nvalid` bytes starting at blk[0].  blk[-4..-1] and blk[64..67] must be readable
 // (staged halo; zero where the corpus has no byte).  `ws` covers every byte of a whitespace
 // character; `alp` is set on the lead byte of an alphabetic character only.
-TRP_HD Cls classify_block(const u8* blk, int nvalid, const UniTables& ut) {
-    Cls c = {0, 0, 0, 0, 0, 0};
+template <class B>
+TRP_HD Cls classify_block(const B& blk, int nvalid, const UniTables& ut) {
+    Cls c = {0, 0, 0, 0, 0, 0, 0};
     u64 high = 0;
     for (int j = 0; j < nvalid; j++) {
         u32 k = ascii_class(blk[j]);
         u64 b = 1ull << j;
+        if (blk[j] == 0x20) c.sp |= b;
         if (k & C_WS) c.ws |= b;
         if (k & C_NL) c.nl |= b;
         if (k & C_CR) c.cr |= b;
@@ -136,16 +164,16 @@ TRP_HD Cls classify_block(const u8* blk, int nvalid, const UniTables& ut) {
         u32 b0 = blk[j];
         u32 cp;
         if (b0 >= 0xC0) {
-            if (decode_lead(blk + j, &cp)) {
+            if (decode_lead(blk, j, &cp)) {
                 if (cp_is_ws_high(cp)) c.ws |= bit(j);
-                else if (cp_is_alpha_high(cp, ut.stage1, ut.stage2, ut.stage1_len)) c.alp |= bit(j);
+                else if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
             }
         } else {
             // continuation byte: it is whitespace iff its character is
             for (int k = 1; k <= 3; k++) {
                 u32 l = blk[j - k];
                 if (l >= 0xC0) {
-                    int n = decode_lead(blk + j - k, &cp);
+                    int n = decode_lead(blk, j - k, &cp);
                     if (n > k && cp_is_ws_high(cp)) c.ws |= bit(j);
                     break;
                 }
@@ -156,15 +184,109 @@ TRP_HD Cls classify_block(const u8* blk, int nvalid, const UniTables& ut) {
     return c;
 }
 
-// Is the byte at q[0] part of a whitespace character?  q[-3..3] must be readable.
-TRP_HD bool byte_is_ws(const u8* q) {
-    u32 b = q[0];
+// ---- bit-sliced classification ------------------------------------------------------------------
+// The 64 bytes of a block are transposed into the eight bit planes of the raw byte values (8x8 bit
+// transposes of byte groups + byte gathers), after which every ASCII class is a short boolean formula
+// evaluated for all 64 bytes at once.  Bytes >= 0x80 are resolved one by one as in classify_block.
+TRP_HD u32 load_u32(const u8* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const u32*>(p);
+#else
+    return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+#endif
+}
+// (a & m) | (b & ~m)
+TRP_HD u32 bfi(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }
+
+// 8x8 bit transpose of the bytes of (lo, hi): afterwards byte c of lo (c < 4) / of hi (c - 4) holds
+// bit c of the eight input bytes, input byte r in bit r.
+TRP_HD void transpose8(u32& lo, u32& hi) {
+    u32 t;
+    t = ((lo >> 7) ^ lo) & 0x00AA00AAu; lo = lo ^ t ^ (t << 7);
+    t = ((hi >> 7) ^ hi) & 0x00AA00AAu; hi = hi ^ t ^ (t << 7);
+    t = ((lo >> 14) ^ lo) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
+    t = ((hi >> 14) ^ hi) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
+    u32 nlo = bfi(0x0F0F0F0Fu, lo, hi << 4);
+    u32 nhi = bfi(0x0F0F0F0Fu, lo >> 4, hi);
+    lo = nlo;
+    hi = nhi;
+}
+// byte `c` of a, b, c2, d packed into one word (a in the low byte)
+TRP_HD u32 gather_byte(u32 a, u32 b, u32 c2, u32 d, int c) {
+    return ((a >> (8 * c)) & 0xFFu) | (((b >> (8 * c)) & 0xFFu) << 8) | (((c2 >> (8 * c)) & 0xFFu) << 16) |
+           (((d >> (8 * c)) & 0xFFu) << 24);
+}
+
+template <class B>
+TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut) {
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) { lo[g] = blk.word(2 * g); hi[g] = blk.word(2 * g + 1); }
+#pragma unroll
+    for (int g = 0; g < 8; g++) transpose8(lo[g], hi[g]);
+    u64 b[8];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        b[c] = (u64)gather_byte(lo[0], lo[1], lo[2], lo[3], c) | ((u64)gather_byte(lo[4], lo[5], lo[6], lo[7], c) << 32);
+        b[c + 4] = (u64)gather_byte(hi[0], hi[1], hi[2], hi[3], c) | ((u64)gather_byte(hi[4], hi[5], hi[6], hi[7], c) << 32);
+    }
+    const u64 V = below(nvalid);
+    const u64 n7 = ~b[7] & V;
+    const u64 lowq = n7 & ~b[6] & ~b[5] & ~b[4];                 // 0x00-0x0F
+    const u64 ctl = lowq & b[3];                                 // 0x08-0x0F
+    Cls c;
+    c.nl = ctl & ~b[2] & b[1] & ~b[0];                           // 0x0A
+    c.cr = ctl & b[2] & ~b[1] & b[0];                            // 0x0D
+    const u64 wsc = ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1]); // 0x09-0x0D
+    const u64 sp = n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]);   // 0x20
+    c.ws = wsc | sp;
+    c.sp = sp;
+    c.dig = n7 & ~b[6] & b[5] & b[4] & ~(b[3] & (b[2] | b[1]));  // 0x30-0x39
+    const u64 nz5 = b[4] | b[3] | b[2] | b[1] | b[0];
+    const u64 gt26 = b[4] & b[3] & (b[2] | (b[1] & b[0]));
+    c.alp = n7 & b[6] & nz5 & ~gt26;                             // A-Z a-z
+    c.pipe = n7 & b[6] & b[5] & b[4] & b[3] & b[2] & ~b[1] & ~b[0];   // 0x7C
+    // Bytes >= 0x80.  Only lead bytes (11xxxxxx) are decoded; a whitespace character marks all its
+    // bytes, an alphabetic one its lead byte.  Continuation bytes at the very start of the block
+    // belong to a character that began in the previous block and are resolved by looking back.
+    const u64 high = b[7] & V;
+    u64 lead = high & b[6];
+    while (lead) {
+        int j = ctz(lead);
+        lead &= lead - 1;
+        u32 cp;
+        int n = decode_lead(blk, j, &cp);
+        if (n) {
+            if (cp_is_ws_high(cp)) c.ws |= below(j + n) & ~below(j) & V;
+            else if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
+        }
+    }
+    u64 head = high & ~b[6] & 7ull;   // continuation bytes among the first three
+    for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
+        u32 cp;
+        for (int k = j + 1; k <= 3; k++) {   // the lead byte is before the block
+            u32 l = blk[j - k];
+            if (l >= 0xC0) {
+                int n = decode_lead(blk, j - k, &cp);
+                if (n > k && cp_is_ws_high(cp)) c.ws |= bit(j);
+                break;
+            }
+            if (l < 0x80) break;
+        }
+    }
+    return c;
+}
+
+// Is the byte q[at] part of a whitespace character?  q[at-3..at+3] must be readable.
+template <class B>
+TRP_HD bool byte_is_ws(const B& q, int at) {
+    u32 b = q[at];
     if (b < 0x80) return (ascii_class(b) & C_WS) != 0;
     u32 cp;
-    if (b >= 0xC0) return decode_lead(q, &cp) && cp_is_ws_high(cp);
+    if (b >= 0xC0) return decode_lead(q, at, &cp) && cp_is_ws_high(cp);
     for (int k = 1; k <= 3; k++) {
-        u32 l = q[-k];
-        if (l >= 0xC0) return decode_lead(q - k, &cp) > k && cp_is_ws_high(cp);
+        u32 l = q[at - k];
+        if (l >= 0xC0) return decode_lead(q, at - k, &cp) > k && cp_is_ws_high(cp);
         if (l < 0x80) return false;
     }
     return false;
@@ -455,6 +577,18 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         s = e;
         is_head = false;
     }
+    // Canonical form: a separator that is emitted in front of byte j while byte j-1 is dropped and
+    // happens to be that very character ('\n' terminator before a kept line, single space before a
+    // table cell) is expressed as "copy byte j-1" instead.  Same output bytes, longer copy runs.
+    {
+        u64 cn = (out.PNL >> 1) & ~out.C & c.nl & d.V;
+        u64 cs = (out.PSP >> 1) & ~out.C & c.sp & d.V & ~(out.PNL >> 1);
+        cn &= (out.C >> 1);   // only where the prefixed byte itself is copied (not a gate-3 marker)
+        cs &= (out.C >> 1);
+        out.C |= cn | cs;
+        out.PNL &= ~(cn << 1);
+        out.PSP &= ~(cs << 1);
+    }
     return out;
 }
 
@@ -538,31 +672,63 @@ TRP_HD ChunkDesc chunk_at(u64 T, u64 j, u32 record, const DevCfg& cfg) {
 // by gap (a gap = the tokens between two alphabetic-bearing tokens); each gap is walked twice, first
 // for its length, then with every token's distance known.
 struct ByteSrc {
-    const u8* p;   // corpus
+    const u8* p;   // corpus (16-byte aligned on the device)
     u64 n;         // corpus length
+    // The device keeps the 16-byte chunk it read last in registers: the walks below are sequential,
+    // so this turns one memory round trip per byte into one per 16 bytes.
+    u64 cbase, clo, chi;
+    TRP_HD u32 get(u64 q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        u64 base = q & ~15ull;
+        if (base != cbase) {
+            if (base + 16 <= n) {
+                uint4 v = *reinterpret_cast<const uint4*>(p + base);
+                clo = (u64)v.x | ((u64)v.y << 32);
+                chi = (u64)v.z | ((u64)v.w << 32);
+            } else {
+                clo = chi = 0;
+                for (u64 i = base; i < n; i++) {
+                    u64 sh = 8 * (i & 7);
+                    if ((i & 8) == 0) clo |= (u64)p[i] << sh; else chi |= (u64)p[i] << sh;
+                }
+            }
+            cbase = base;
+        }
+        u64 w = (q & 8) ? chi : clo;
+        return (u32)(w >> (8 * (q & 7))) & 0xFFu;
+#else
+        return p[q];
+#endif
+    }
 };
+TRP_HD ByteSrc make_src(const u8* p, u64 n) {
+    ByteSrc s;
+    s.p = p; s.n = n; s.cbase = ~0ull; s.clo = 0; s.chi = 0;
+    return s;
+}
 struct TokInfo {
     u64 ts, te;   // [ts, te) byte range, te == ts: no token
     u32 digits;
     bool alpha;
 };
-TRP_HD u32 char_at(const ByteSrc& s, u64 q, u64 end, int* len, const UniTables& ut) {
+TRP_HD u32 char_at(ByteSrc& s, u64 q, u64 end, int* len, const UniTables& ut) {
     // class code of the character starting at q (q < end); *len = its byte length
-    u32 b = s.p[q];
+    u32 b = s.get(q);
     if (b < 0x80) { *len = 1; return ascii_class(b); }
     *len = 1;
     if (b < 0xC0) return 0;
     u8 tmp[4] = {(u8)b, 0, 0, 0};
-    for (int i = 1; i < 4; i++) tmp[i] = (q + i < end) ? s.p[q + i] : 0;
+    for (int i = 1; i < 4; i++) tmp[i] = (q + i < end) ? (u8)s.get(q + i) : 0;
     u32 cp;
-    int n = decode_lead(tmp, &cp);
+    PlainBlk tb = {tmp};
+    int n = decode_lead(tb, 0, &cp);
     if (!n) return 0;
     *len = n;
     if (cp_is_ws_high(cp)) return C_WS;
-    if (cp_is_alpha_high(cp, ut.stage1, ut.stage2, ut.stage1_len)) return C_ALPHA;
+    if (cp_is_alpha_high(cp, ut)) return C_ALPHA;
     return 0;
 }
-TRP_HD TokInfo next_token(const ByteSrc& s, u64 pos, u64 end, bool table, const UniTables& ut) {
+TRP_HD TokInfo next_token(ByteSrc& s, u64 pos, u64 end, bool table, const UniTables& ut) {
     TokInfo t;
     t.digits = 0;
     t.alpha = false;
@@ -588,7 +754,7 @@ TRP_HD TokInfo next_token(const ByteSrc& s, u64 pos, u64 end, bool table, const 
 // Calls f(token, keep) for every token of the line [p, e) in order.  Pass K = ~0 to get the digit
 // sum / count of the tokens at distance exactly `probe` instead (no callback use).
 template <class F>
-TRP_HD void g3_walk(const ByteSrc& s, u64 p, u64 e, bool table, const UniTables& ut, u64 K, u64 probe,
+TRP_HD void g3_walk(ByteSrc& s, u64 p, u64 e, bool table, const UniTables& ut, u64 K, u64 probe,
                     u64* wave_digits, u64* wave_count, F f) {
     u64 pos = p;
     bool left_alpha = false;
@@ -630,7 +796,7 @@ struct NoTok {
 };
 
 // Number of accepted waves for the line [p, e).
-TRP_HD u64 g3_solve_K(const ByteSrc& s, u64 p, u64 e, bool table, float max_ratio, const UniTables& ut) {
+TRP_HD u64 g3_solve_K(ByteSrc& s, u64 p, u64 e, bool table, float max_ratio, const UniTables& ut) {
     // seed totals: digits and alphabetic chars of the alphabetic-bearing tokens
     u64 d = 0, a = 0;
     {

@@ -84,7 +84,7 @@ struct PlanBits {
 int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const sim_config* scfg,
                   sim_result* out, int tile_blocks) {
     DevCfg cfg = to_dev(scfg);
-    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN};
+    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
     const u64 N = offsets[R];
     const u64 nB = (N + 63) / 64;
     if (tile_blocks <= 0) tile_blocks = TILE_BLOCKS;
@@ -102,7 +102,13 @@ int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, con
     for (u64 b = 0; b < nB; b++) {
         u64 p = b * 64;
         int nvalid = (int)((N - p) < 64 ? (N - p) : 64);
-        cls[b] = classify_block(base + p, nvalid, ut);
+        cls[b] = classify_block_fast(PlainBlk{base + p}, nvalid, ut);
+        {   // the bit-sliced classifier must agree with the byte-by-byte one
+            Cls ref = classify_block(PlainBlk{base + p}, nvalid, ut);
+            if (ref.ws != cls[b].ws || ref.nl != cls[b].nl || ref.cr != cls[b].cr || ref.pipe != cls[b].pipe ||
+                ref.dig != cls[b].dig || ref.alp != cls[b].alp)
+                return -100;
+        }
         Vm[b] = below(nvalid);
     }
 
@@ -153,7 +159,7 @@ int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, con
             }
         }
         // pending digit-heavy lines (markers): solve serially
-        ByteSrc src = {base, N};
+        ByteSrc src = make_src(base, N);
         PlanBits pb = {&plan};
         for (u64 b = 0; b < nB; b++) {
             u64 marks = plan[b].TOK & ~plan[b].C;
@@ -271,6 +277,27 @@ void trp_sim_free(sim_result* r) {
     free(r->denoised); free(r->denoised_offsets); free(r->dropped); free(r->tok_start);
     free(r->tok_len); free(r->tok_offsets); free(r->chunks); free(r->chunk_offsets);
     memset(r, 0, sizeof(*r));
+}
+
+// The range shortcuts of cp_is_alpha_high must agree with the table: returns the number of code
+// points where the function differs from a plain table lookup.
+extern "C" int trp_sim_check_alpha_shortcut() {
+    int bad = 0;
+    for (u32 cp = 0x80; cp < 0x110000; cp++) {
+        u32 blk = cp >> 8;
+        bool t = false;
+        if (blk < TRP_ALPHA_STAGE1_LEN) {
+            u32 row = trp_alpha_stage1[blk], o = cp & 255u;
+            t = (trp_alpha_stage2[row * 8 + (o >> 5)] >> (o & 31u)) & 1u;
+        }
+        UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
+        if (t != cp_is_alpha_high(cp, ut)) bad++;
+        u32 low[64];
+        for (int i = 0; i < 64; i++) low[i] = trp_alpha_stage2[trp_alpha_stage1[i >> 3] * 8 + (i & 7)];
+        UniTables ul = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, low};
+        if (t != cp_is_alpha_high(cp, ul)) bad++;
+    }
+    return bad;
 }
 
 // Brute-force associativity check of the two monoids on random elements; returns the number of

@@ -141,6 +141,15 @@ def test_edge_batches(T, ctx):
             assert_same(exp, got, recs, repr(recs)[:60])
 
 
+def test_many_digit_heavy_lines_grow_the_work_list(T, ctx):
+    """more gate-3 lines than the optimistic work list holds: the batch is re-run with the exact size"""
+    recs = [b"12 ab 34\n" * 20000, b"7 x 9 9\n| 5 | y | 77 |\n" * 15000, b"plain words only\n" * 10]
+    exp, got = _run(T, ctx, recs, (True, 0.35, True, 64, (8,), 16))
+    assert_same(exp, got, recs, "g3list")
+    exp, got = _run(T, ctx, recs, (True, 0.35, True, 64, (8,), 16))   # second call: buffer already large
+    assert_same(exp, got, recs, "g3list2")
+
+
 def test_long_records_and_multiple_overlaps(T, ctx):
     import random
     rng = random.Random(7)

@@ -23,6 +23,10 @@ def _golden_records():
     return recs
 
 
+def test_alpha_range_shortcut_matches_table():
+    assert S.lib().trp_sim_check_alpha_shortcut() == 0
+
+
 def test_monoids_are_associative():
     assert S.lib().trp_sim_check_monoids(12345, 200000) == 0
 
