@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--config", default="B", choices=["B", "C", "D"])
     ap.add_argument("--no-denoise", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time trp_preprocess_batch on host buffers (PCIe both ways included)")
     args = ap.parse_args()
 
     import numpy as np
@@ -148,7 +150,7 @@ def main():
     if os.path.exists(tr):
         try:
             with open(tr) as f:
-                roofline["traffic"] = json.load(f).get(dominant)
+                roofline["traffic"] = (json.load(f).get(dominant) or {}).get("bytes")
         except Exception:
             pass
 
@@ -165,6 +167,25 @@ def main():
         "roofline": roofline,
         "corpus_generation_s": round(gen_s, 2),
     }
+
+    # ---- the same batch handed over in host memory: H2D of the input and D2H of every result array -----
+    if args.host_path and rank == 0:
+        pinned = torch.from_numpy(data).pin_memory()
+        offs64 = np.ascontiguousarray(offs, dtype=np.uint64)
+        L = T.load_library()
+        cfg = T._make_cfg(den, st)
+        best = None
+        for _ in range(3):
+            r = T._Result()
+            t0 = time.perf_counter()
+            rc = L.trp_preprocess_batch(ctx._h, pinned.data_ptr(), offs64.ctypes.data, R, C.byref(cfg), C.byref(r))
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                raise SystemExit("trp_preprocess_batch failed: %d" % rc)
+            L.trp_result_free(C.byref(r))
+            best = dt if best is None else min(best, dt)
+        out["host_path"] = {"value": round(N / best / 1e9, 3), "unit": "GB/s", "ms": round(best * 1e3, 2),
+                            "note": "pinned input, H2D + kernels + D2H of all result arrays, best of 3"}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -114,6 +114,10 @@ void* trp_stream(trp_ctx* ctx);
 int trp_preprocess_batch(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets,
                          uint64_t n_records, const trp_config* cfg, trp_result* out);
 void trp_result_free(trp_result* r);
+/* Large host result arrays are page-locked blocks that trp_result_free / trp_free return to a
+ * process-wide pool for the next call (up to 16 GiB stays pooled).  trp_trim_host_pool unpins and frees
+ * the blocks that are not in use.  No counterpart in the reference (its results are heap Strings). */
+void trp_trim_host_pool(void);
 
 /* Same path with the batch already resident in GPU memory (16-byte aligned `d_bytes`, device
  * `d_offsets`).  The result arrays are device pointers into buffers owned by the context; they stay

@@ -22,7 +22,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "triplets_amd.h"
@@ -1642,14 +1645,86 @@ int trp_copy_to_host(trp_ctx* c, void* dst, const void* d_src, size_t bytes) {
     return TRP_OK;
 }
 
+// Host result arrays.  Large arrays live in page-locked memory so that the device-to-host copies run
+// at link speed; the blocks are recycled through a process-wide pool (pinning is expensive), small
+// arrays come from malloc.  host_release accepts pointers of either kind.
+namespace {
+struct HostPool {
+    static constexpr size_t PIN_MIN = 256u << 10;          // smaller arrays are not worth pinning
+    static constexpr size_t KEEP_MAX = (size_t)16 << 30;   // free pinned bytes kept for reuse
+    std::mutex mu;
+    std::unordered_map<void*, size_t> live;                // pinned blocks handed out -> capacity
+    std::vector<std::pair<void*, size_t>> idle;            // pinned blocks ready for reuse
+    size_t idle_bytes = 0;
+
+    void* alloc(size_t n) {
+        if (n < PIN_MIN) return malloc(n ? n : 1);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].second >= n && idle[i].second <= 2 * n + (1u << 20) &&
+                    (best == idle.size() || idle[i].second < idle[best].second))
+                    best = i;
+            if (best != idle.size()) {
+                auto blk = idle[best];
+                idle.erase(idle.begin() + best);
+                idle_bytes -= blk.second;
+                live[blk.first] = blk.second;
+                return blk.first;
+            }
+        }
+        const size_t cap = (n + n / 8 + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return malloc(n);   // pageable memory still works, only slower
+        }
+        std::lock_guard<std::mutex> g(mu);
+        live[p] = cap;
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        bool drop = false;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = live.find(p);
+            if (it == live.end()) { free(p); return; }
+            const size_t cap = it->second;
+            live.erase(it);
+            if (idle_bytes + cap <= KEEP_MAX) { idle.emplace_back(p, cap); idle_bytes += cap; }
+            else drop = true;
+        }
+        if (drop) (void)hipHostFree(p);
+    }
+    void trim() {
+        std::vector<std::pair<void*, size_t>> blocks;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            blocks.swap(idle);
+            idle_bytes = 0;
+        }
+        for (auto& b : blocks) (void)hipHostFree(b.first);
+    }
+};
+HostPool& host_pool() {
+    static HostPool* pool = new HostPool();   // never destroyed: results may outlive static teardown
+    return *pool;
+}
+}  // namespace
+
 void trp_result_free(trp_result* r) {
     if (!r) return;
-    free(r->denoised); free(r->denoised_offsets); free(r->dropped); free(r->tok_start); free(r->tok_len);
-    free(r->tok_offsets); free(r->chunks); free(r->chunk_offsets);
+    HostPool& hp = host_pool();
+    hp.release(r->denoised); hp.release(r->denoised_offsets); hp.release(r->dropped); hp.release(r->tok_start);
+    hp.release(r->tok_len); hp.release(r->tok_offsets); hp.release(r->chunks); hp.release(r->chunk_offsets);
     memset(r, 0, sizeof(*r));
 }
 
-void trp_free(void* p) { free(p); }
+void trp_free(void* p) { host_pool().release(p); }
+
+void trp_trim_host_pool(void) { host_pool().trim(); }
 
 int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const trp_config* cfg,
                          trp_result* out) {
@@ -1669,7 +1744,7 @@ int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
     memset(out, 0, sizeof(*out));
     out->n_records = R; out->n_denoised = d.n_denoised; out->n_tokens = d.n_tokens; out->n_chunks = d.n_chunks;
     auto grab = [&](void** dst, const void* src, size_t bytes_) -> int {
-        *dst = malloc(bytes_ ? bytes_ : 1);
+        *dst = host_pool().alloc(bytes_);
         if (!*dst) return fail(TRP_E_ARG, "out of host memory");
         if (bytes_) {
             hipError_t e = hipMemcpyAsync(*dst, src, bytes_, hipMemcpyDeviceToHost, c->stream);
@@ -1727,7 +1802,7 @@ int trp_tokenize(trp_ctx* c, const uint8_t* text, size_t len, uint32_t** starts,
 int trp_token_count(trp_ctx* c, const uint8_t* text, size_t len, size_t* n_tokens) {
     uint32_t *s = nullptr, *l = nullptr;
     int rc = trp_tokenize(c, text, len, &s, &l, n_tokens);
-    free(s); free(l);
+    trp_free(s); trp_free(l);
     return rc;
 }
 

@@ -1,0 +1,75 @@
+//! Raw declarations of include/triplets_amd.h.  Field order and widths must match the header.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const TRP_OK: c_int = 0;
+
+#[repr(C)]
+pub struct trp_ctx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct trp_config {
+    pub denoise_enabled: u8,
+    pub strip_markdown: u8,
+    pub max_digit_ratio: f32,
+    pub max_window_tokens: u32,
+    pub overlaps: *const u32,
+    pub n_overlaps: u32,
+    pub summary_fallback_tokens: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct trp_chunk {
+    pub record: u32,
+    pub kind: u32,
+    pub index: u32,
+    pub overlap: u32,
+    pub span: u32,
+    pub tok_begin: u32,
+    pub tok_end: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+pub struct trp_result {
+    pub denoised: *mut u8,
+    pub denoised_offsets: *mut u64,
+    pub dropped: *mut u8,
+    pub tok_start: *mut u32,
+    pub tok_len: *mut u32,
+    pub tok_offsets: *mut u64,
+    pub chunks: *mut trp_chunk,
+    pub chunk_offsets: *mut u64,
+    pub n_records: u64,
+    pub n_denoised: u64,
+    pub n_tokens: u64,
+    pub n_chunks: u64,
+}
+
+extern "C" {
+    pub fn trp_create(device: c_int, out: *mut *mut trp_ctx) -> c_int;
+    pub fn trp_destroy(ctx: *mut trp_ctx);
+    pub fn trp_last_error() -> *const c_char;
+    pub fn trp_preprocess_batch(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        cfg: *const trp_config,
+        out: *mut trp_result,
+    ) -> c_int;
+    pub fn trp_result_free(r: *mut trp_result);
+    pub fn trp_denoise(
+        ctx: *mut trp_ctx,
+        text: *const u8,
+        len: usize,
+        cfg: *const trp_config,
+        out: *mut *mut u8,
+        out_len: *mut usize,
+    ) -> c_int;
+    pub fn trp_token_count(ctx: *mut trp_ctx, text: *const u8, len: usize, n: *mut usize) -> c_int;
+    pub fn trp_free(p: *mut c_void);
+}

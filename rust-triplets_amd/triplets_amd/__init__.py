@@ -59,7 +59,7 @@ CHUNK_DTYPE = np.dtype([(n, "<u4") for n in
 EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_preprocess_batch",
            "trp_result_free", "trp_preprocess_batch_device", "trp_copy_to_host",
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
-           "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile"]
+           "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool"]
 
 _lib = None
 
@@ -177,6 +177,79 @@ class BatchResult:
             s = int(self.tok_start[t0 + k])
             parts.append(self.denoised[s:s + int(self.tok_len[t0 + k])].tobytes())
         return b" ".join(parts)
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharding by record range (records are independent: no exchange between shards)
+# ---------------------------------------------------------------------------------------------------
+def shard_ranges(offsets: np.ndarray, n_shards: int):
+    """Byte-balanced contiguous record ranges [(r0, r1), ...], one per shard: shard k starts at the
+    first record whose start offset is >= k*N/n_shards."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    R = len(offsets) - 1
+    N = int(offsets[-1]) if R >= 0 and len(offsets) else 0
+    cuts = [0]
+    for k in range(1, n_shards):
+        target = (N * k) // n_shards
+        cuts.append(int(np.searchsorted(offsets[:R + 1], np.uint64(target), side="left")))
+    cuts.append(R)
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[i], cuts[i + 1]) for i in range(n_shards)]
+
+
+def shard_slice(data: np.ndarray, offsets: np.ndarray, r0: int, r1: int):
+    """The packed sub-batch of records [r0, r1): (bytes view, offsets rebased to 0)."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    b0, b1 = int(offsets[r0]), int(offsets[r1])
+    return data[b0:b1], (offsets[r0:r1 + 1] - np.uint64(b0)).astype(np.uint64)
+
+
+def concat_results(parts: Sequence["BatchResult"]) -> "BatchResult":
+    """Result of the whole batch from the results of its shards, in shard order.  Offsets are shifted
+    by the totals of the preceding shards; token starts become u64 because the concatenated text may
+    exceed the single-batch limit."""
+    den, doff, drop, ts, tl, toff, ch, coff = [], [np.zeros(1, np.uint64)], [], [], [], \
+        [np.zeros(1, np.uint64)], [], [np.zeros(1, np.uint64)]
+    base_d = base_t = base_c = base_r = 0
+    for p in parts:
+        den.append(p.denoised)
+        doff.append(p.denoised_offsets[1:] + np.uint64(base_d))
+        drop.append(p.dropped)
+        ts.append(p.tok_start.astype(np.uint64) + np.uint64(base_d))
+        tl.append(p.tok_len)
+        toff.append(p.tok_offsets[1:] + np.uint64(base_t))
+        c = p.chunks.copy()
+        c["record"] += np.uint32(base_r)
+        ch.append(c)
+        coff.append(p.chunk_offsets[1:] + np.uint64(base_c))
+        base_d += int(p.n_denoised)
+        base_t += int(p.n_tokens)
+        base_c += int(p.n_chunks)
+        base_r += int(p.n_records)
+
+    def cat(xs, dt):
+        return np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
+
+    return BatchResult(denoised=cat(den, np.uint8), denoised_offsets=cat(doff, np.uint64),
+                       dropped=cat(drop, np.uint8), tok_start=cat(ts, np.uint64), tok_len=cat(tl, np.uint32),
+                       tok_offsets=cat(toff, np.uint64), chunks=cat(ch, CHUNK_DTYPE),
+                       chunk_offsets=cat(coff, np.uint64), n_records=base_r, n_denoised=base_d,
+                       n_tokens=base_t, n_chunks=base_c)
+
+
+def gather_shards(local: "BatchResult", group=None) -> Optional["BatchResult"]:
+    """Collect the shard results of all ranks of a torch.distributed group on rank 0 (in rank order)
+    and concatenate them.  Outside the timed path: this is result plumbing, not a data-path collective.
+    Returns the whole-batch result on rank 0 and None elsewhere."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    box = [None] * world if rank == 0 else None
+    dist.gather_object(local.__dict__, box, dst=0, group=group)
+    if rank != 0:
+        return None
+    return concat_results([BatchResult(**d) for d in box])
 
 
 class DeviceResult:

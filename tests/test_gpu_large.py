@@ -1,0 +1,156 @@
+"""Parity at the benchmark's full sizes (1e9-byte batches) through size-independent properties.
+
+The oracle needs ~10 s per GB per core, so the full batch is checked by
+  * exact comparison with the oracle on sample record ranges (first, middle, last, and the records around
+    the largest one), and
+  * properties that hold for any input:
+      - the token table of the denoising pass equals the token table the pass-through path computes on
+        the denoised text (two independent kernel paths; `split_whitespace` of the same bytes),
+      - records are independent: two half-batches concatenated equal the whole batch,
+      - chunk descriptors follow the closed-form window arithmetic of the per-record token counts,
+      - offsets arrays are monotone and consistent with the totals, dropped <=> empty text.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import triplets_amd as T
+from parity import assert_same
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "corpusgen"))
+
+pytestmark = pytest.mark.gpu
+
+SIZE = int(os.environ.get("TRP_LARGE_BYTES", "1000000000"))
+
+
+def slice_result(res, a, b):
+    """Records [a, b) of a whole-batch result as a stand-alone result."""
+    d0, d1 = int(res.denoised_offsets[a]), int(res.denoised_offsets[b])
+    t0, t1 = int(res.tok_offsets[a]), int(res.tok_offsets[b])
+    c0, c1 = int(res.chunk_offsets[a]), int(res.chunk_offsets[b])
+    ch = res.chunks[c0:c1].copy()
+    ch["record"] -= np.uint32(a)
+    return T.BatchResult(
+        denoised=res.denoised[d0:d1], denoised_offsets=res.denoised_offsets[a:b + 1] - np.uint64(d0),
+        dropped=res.dropped[a:b], tok_start=res.tok_start[t0:t1] - np.uint32(d0), tok_len=res.tok_len[t0:t1],
+        tok_offsets=res.tok_offsets[a:b + 1] - np.uint64(t0), chunks=ch,
+        chunk_offsets=res.chunk_offsets[a:b + 1] - np.uint64(c0), n_records=b - a, n_denoised=d1 - d0,
+        n_tokens=t1 - t0, n_chunks=c1 - c0)
+
+
+def expected_chunk_counts(T_r, mwt, overlaps, sft):
+    T_r = T_r.astype(np.int64)
+    span = np.minimum(mwt, T_r)
+    multi = (T_r > 0) & (span < T_r)
+    n = np.where((T_r > 0) & ~multi, 1, 0).astype(np.int64)
+    for ov in overlaps:
+        stride = np.where(span >= ov, np.maximum(1, span - ov), 1)
+        wins = 1 + -(-(T_r - span) // np.maximum(stride, 1))
+        n += np.where(multi, wins, 0)
+    if sft > 0:
+        n += np.where(multi & (T_r > mwt), 1, 0)
+    return n
+
+
+def check_batch(name, data, offs, overlaps, sample_bytes=6_000_000):
+    R = len(offs) - 1
+    N = int(offs[-1])
+    den = T.DenoiserConfig(True, 0.35, True)
+    st = T.ChunkingStrategy(1024, list(overlaps), 0.35, 512)
+    ocfg = O.make_config(True, 0.35, True, 1024, tuple(overlaps), 512)
+    ctx = T.Context(0)
+    import torch
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    dev = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
+    res = dev.to_host()
+
+    # ---- structure -----------------------------------------------------------------------------------
+    for k, total in (("denoised_offsets", res.n_denoised), ("tok_offsets", res.n_tokens),
+                     ("chunk_offsets", res.n_chunks)):
+        a = getattr(res, k)
+        assert a[0] == 0 and int(a[-1]) == total, (name, k)
+        assert np.all(a[1:] >= a[:-1]), (name, k)
+    sizes = np.diff(res.denoised_offsets.astype(np.int64))
+    assert np.array_equal(res.dropped != 0, sizes == 0), name
+    T_r = np.diff(res.tok_offsets.astype(np.int64))
+    assert np.all(T_r[res.dropped != 0] == 0)
+    assert np.all(res.tok_len > 0)
+    ends = res.tok_start.astype(np.int64) + res.tok_len
+    assert np.all(res.tok_start[1:].astype(np.int64) > ends[:-1] - 1), "tokens overlap or are unordered"
+    assert int(ends[-1]) <= res.n_denoised
+
+    # ---- chunk arithmetic --------------------------------------------------------------------------------
+    got_counts = np.diff(res.chunk_offsets.astype(np.int64))
+    assert np.array_equal(got_counts, expected_chunk_counts(T_r, 1024, overlaps, 512)), name
+    ch = res.chunks
+    assert np.all(ch["tok_end"] > ch["tok_begin"])
+    assert np.all(ch["tok_end"].astype(np.int64) <= T_r[ch["record"]])
+    assert np.all(np.diff(ch["record"].astype(np.int64)) >= 0)
+    win = ch[ch["kind"] == 0]
+    assert np.all(win["tok_end"] - win["tok_begin"] <= win["span"])
+
+    # ---- exact comparison with the oracle on sample ranges --------------------------------------------
+    big = int(np.argmax(np.diff(offs.astype(np.int64))))
+    starts = sorted({0, R // 2, max(0, big - 2)})
+    ranges = []
+    for a in starts:
+        b = int(np.searchsorted(offs, offs[a] + np.uint64(sample_bytes), side="left"))
+        ranges.append((a, max(a + 1, min(b, R))))
+    a_last = int(np.searchsorted(offs, np.uint64(max(0, N - sample_bytes)), side="left"))
+    ranges.append((min(a_last, R - 1), R))
+    for a, b in ranges:
+        d, o = T.shard_slice(data, offs, a, b)
+        exp = O.batch(d, o, ocfg, n_threads=8)
+        assert_same(exp, slice_result(res, a, b), None, "%s records [%d,%d)" % (name, a, b))
+
+    # ---- the token table equals split_whitespace of the denoised text (pass-through path) --------------
+    d_den = torch.from_numpy(res.denoised).cuda()
+    d_doff = torch.from_numpy(res.denoised_offsets.astype(np.int64)).cuda()
+    thru = ctx.preprocess_batch_device(d_den.data_ptr(), d_doff.data_ptr(), R, res.n_denoised,
+                                       T.DenoiserConfig(False, 0.35, True), st)
+    assert int(thru.n_tokens) == res.n_tokens
+    assert np.array_equal(thru.fetch("tok_start", thru.n_tokens, np.uint32), res.tok_start)
+    assert np.array_equal(thru.fetch("tok_len", thru.n_tokens, np.uint32), res.tok_len)
+    assert np.array_equal(thru.fetch("tok_offsets", R + 1, np.uint64), res.tok_offsets)
+    assert np.array_equal(thru.fetch("chunk_offsets", R + 1, np.uint64), res.chunk_offsets)
+    del d_den, d_doff
+
+    # ---- record independence: two halves concatenated equal the whole ----------------------------------
+    parts = []
+    for r0, r1 in T.shard_ranges(offs, 2):
+        b0, b1 = int(offs[r0]), int(offs[r1])
+        sub_offs = torch.from_numpy((offs[r0:r1 + 1] - np.uint64(b0)).astype(np.int64)).cuda()
+        # the device variant wants a 16-byte aligned text pointer: copy the half to a fresh buffer
+        sub = d_bytes[b0:b1].clone()
+        h = ctx.preprocess_batch_device(sub.data_ptr(), sub_offs.data_ptr(), r1 - r0, b1 - b0, den, st)
+        parts.append(h.to_host())
+    assert_same(res, T.concat_results(parts), None, name + " halves")
+    ctx.close()
+    return res
+
+
+def test_config_b_full_size():
+    import corpusgen
+    data, offs = corpusgen.config_b(SIZE, 42, 16)
+    res = check_batch("config B", data, offs, (64,))
+    # clean English: nothing is dropped, one window per record
+    assert res.n_chunks == len(offs) - 1
+
+
+def test_config_c_one_gigabyte():
+    import corpusgen
+    data, offs = corpusgen.config_c(SIZE, 43, 16)
+    check_batch("config C", data, offs, (64,))
+
+
+def test_config_d_skewed_two_overlaps():
+    import corpusgen
+    data, offs = corpusgen.config_d(SIZE, 44, 16)
+    res = check_batch("config D", data, offs, (64, 256))
+    assert res.n_chunks > len(offs) - 1      # the 1 MiB records have many windows

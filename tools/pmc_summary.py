@@ -1,25 +1,63 @@
 #!/usr/bin/env python3
-"""Aggregate a rocprofv3 --pmc counter_collection.csv per kernel (average per dispatch)."""
+"""Aggregate rocprofv3 --pmc counter_collection.csv files per kernel (average per dispatch).
+
+  pmc_summary.py DIR                         print every counter of every kernel
+  pmc_summary.py --traffic FETCH_DIR WRITE_DIR OUT.json
+        HBM bytes per launch of each kernel from two separate passes, one with FETCH_SIZE and one
+        with WRITE_SIZE.  Both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests
+        of wide coalesced reads at 64 bytes, so the read side is doubled.
+"""
 import csv
 import glob
+import json
 import sys
 from collections import defaultdict
 
 
-def main(d):
+def short_name(full):
+    k = full.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return k.strip()
+
+
+def load(d):
     acc = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                k = short_name(row["Kernel_Name"])
                 acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 cnt[k][row["Counter_Name"]] += 1
-    for k in sorted(acc):
+    return {k: {c: acc[k][c] / cnt[k][c] for c in acc[k]} for k in acc}, cnt
+
+
+def main(argv):
+    if argv[1] == "--traffic":
+        fetch, _ = load(argv[2])
+        write, _ = load(argv[3])
+        out = {}
+        for k in sorted(set(fetch) | set(write)):
+            rd = 2.0 * fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
+            wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+            base = k.split("<")[0]
+            e = out.setdefault(base, {"read_bytes": 0.0, "write_bytes": 0.0})
+            # template instances of one kernel that both ran are reported under their full names too
+            e["read_bytes"] = max(e["read_bytes"], rd)
+            e["write_bytes"] = max(e["write_bytes"], wr)
+            out[k] = {"read_bytes": rd, "write_bytes": wr}
+        for e in out.values():
+            e["bytes"] = e["read_bytes"] + e["write_bytes"]
+        with open(argv[4], "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        for k, e in sorted(out.items()):
+            print("%-28s read %14.0f  write %14.0f  total %14.0f" % (k, e["read_bytes"], e["write_bytes"], e["bytes"]))
+        return
+    avg, cnt = load(argv[1])
+    for k in sorted(avg):
         print(k)
-        for c in sorted(acc[k]):
-            print("   %-28s %16.0f  (avg of %d dispatches)" % (c, acc[k][c] / cnt[k][c], cnt[k][c]))
+        for c in sorted(avg[k]):
+            print("   %-28s %16.0f  (avg of %d dispatches)" % (c, avg[k][c], cnt[k][c]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv)
