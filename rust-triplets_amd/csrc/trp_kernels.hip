@@ -145,6 +145,89 @@ __device__ inline T block_scan_excl_bwd(T v, Op op, T identity, T seed, T* smem)
     return res;
 }
 
+// ---- wave-uniform summaries from ballots -------------------------------------------------------------
+// The forward summary J of the 64 blocks of a wavefront, computed without moving data between lanes:
+// counts are summed as popcounts of the ballots of their bit planes (a block holds at most 64 of
+// anything, so seven planes), flags come from ballots directly.  The result is the same value as the
+// ordered fold of j_combine over the lanes and is uniform across the wave.
+struct LineSumBallots {
+    u64 d[7], a[7], p[7];
+    u64 nz, first_pipe, last_pipe, seen;
+};
+__device__ inline LineSumBallots ballots_of(const LineSum& x) {
+    LineSumBallots B;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        B.d[k] = __ballot((x.d >> k) & 1u);
+        B.a[k] = __ballot((x.a >> k) & 1u);
+        B.p[k] = __ballot((x.p >> k) & 1u);
+    }
+    B.nz = __ballot(ls_first(x) != 0);
+    B.first_pipe = __ballot(ls_first(x) == 1u);
+    B.last_pipe = __ballot(ls_last(x) == 1u);
+    B.seen = __ballot(ls_seen_text(x));
+    return B;
+}
+// Sum (in lane order) of the LineSums of the lanes in mask m.
+__device__ inline LineSum ballots_sum(const LineSumBallots& B, u64 m) {
+    LineSum s = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        s.d += (u32)popc(B.d[k] & m) << k;
+        s.a += (u32)popc(B.a[k] & m) << k;
+        s.p += (u32)popc(B.p[k] & m) << k;
+    }
+    const u64 nz = B.nz & m;
+    if (nz) {
+        const u32 first = ((B.first_pipe >> ctz(nz)) & 1ull) ? 1u : 2u;
+        const u32 last = ((B.last_pipe >> top(nz)) & 1ull) ? 1u : 2u;
+        s.f = first | (last << 2) | ((B.seen & m) ? 16u : 0u);
+    }
+    return s;
+}
+__device__ inline u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ inline LineSum readlane_ls(const LineSum& x, int lane) {
+    LineSum r = {readlane_u32(x.d, lane), readlane_u32(x.a, lane), readlane_u32(x.p, lane), readlane_u32(x.f, lane)};
+    return r;
+}
+
+__device__ inline J wave_J(const J& j) {
+    const u64 lsm = __ballot((j.g & G_LS) != 0), rsm = __ballot((j.g & G_RS) != 0);
+    const u64 gah = __ballot((j.g & G_AH) != 0), gat = __ballot((j.g & G_AT) != 0);
+    const LineSumBallots B = ballots_of(j.head);
+    J r;
+    u32 g = 0;
+    if (!lsm) {
+        r.head = ballots_sum(B, ~0ull);
+        r.tail = ls_empty();
+    } else {
+        const int f = ctz(lsm), l = top(lsm);
+        r.head = ballots_sum(B, below(f + 1));
+        r.tail = ls_add(readlane_ls(j.tail, l), ballots_sum(B, ~below(l + 1)));
+        g |= G_LS;
+        const bool c0l = (__ballot((j.g & G_C0) != 0) >> l) & 1ull, c1l = (__ballot((j.g & G_C1) != 0) >> l) & 1ull;
+        const u64 rs_before = rsm & below(l);
+        bool known;
+        if (rs_before) {
+            const int r0 = top(rs_before);
+            known = ((gat >> r0) & 1ull) || (gah & below(l) & ~below(r0 + 1)) != 0;
+        } else {
+            known = (gah & below(l)) != 0;
+            if (c1l) g |= G_C1;
+        }
+        if (c0l || (c1l && known)) g |= G_C0;
+    }
+    if (!rsm) {
+        if (gah) g |= G_AH | G_AT;
+    } else {
+        g |= G_RS;
+        if (gah & below(ctz(rsm) + 1)) g |= G_AH;
+        if (gat & ~below(top(rsm))) g |= G_AT;
+    }
+    r.g = g;
+    return r;
+}
+
 struct JOp { __device__ J operator()(const J& a, const J& b) const { return j_combine(a, b); } };
 struct SOp { __device__ S operator()(const S& a, const S& b) const { return s_combine(a, b); } };
 
@@ -174,22 +257,44 @@ __device__ inline uint4 load16_guarded(const u8* __restrict__ g, u64 N, u64 q) {
     return v;
 }
 
-// Copy the tile [tS, tS+TILE) plus HALO bytes on both sides into LDS (zeros outside the corpus).
-__device__ inline void stage_tile(const u8* __restrict__ g, u64 N, u64 tS, u8* sb) {
+// A tile [tS, tS+TILE) plus HALO bytes on both sides travels from global memory to the LDS image in two
+// steps, so that the loads of the next tile can be in flight while the current one is processed.
+struct TileRegs {
+    uint4 v[TILE / 16 / NT];
+    uint4 halo;   // thread 0: the 16 bytes before the tile; thread 1: the 16 bytes after it
+};
+__device__ inline void tile_load(const u8* __restrict__ g, u64 N, u64 tS, TileRegs& r) {
+    const int tid = threadIdx.x;
+    if (tS >= HALO && tS + TILE + HALO <= N) {
+        // interior tile (uniform branch): straight-line loads, all in flight together
+        const uint4* src = reinterpret_cast<const uint4*>(g + tS);
+#pragma unroll
+        for (int k = 0; k < TILE / 16 / NT; k++) r.v[k] = src[k * NT + tid];
+        r.halo = make_uint4(0, 0, 0, 0);
+        if (tid < 2) r.halo = *reinterpret_cast<const uint4*>(g + (tid == 0 ? tS - HALO : tS + TILE));
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < TILE / 16 / NT; k++) r.v[k] = load16_guarded(g, N, tS + (u64)(k * NT + tid) * 16);
+    r.halo = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { if (tS >= HALO) r.halo = load16_guarded(g, N, tS - HALO); }
+    else if (tid == 1) r.halo = load16_guarded(g, N, tS + TILE);
+}
+__device__ inline void tile_store(const TileRegs& r, u8* sb) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < TILE / 16 / NT; k++) {
-        int c = k * NT + tid;
-        uint4 v = load16_guarded(g, N, tS + (u64)c * 16);
-        lds_store16(sb + ((c >> 2) + 1) * PAD_STRIDE + (c & 3) * 16, v);
+        const int c = k * NT + tid;
+        lds_store16(sb + ((c >> 2) + 1) * PAD_STRIDE + (c & 3) * 16, r.v[k]);
     }
-    if (tid == 0) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (tS >= HALO) v = load16_guarded(g, N, tS - HALO);
-        lds_store16(sb + 48, v);                                     // last 16 bytes of block -1
-    } else if (tid == 1) {
-        lds_store16(sb + (TILE_BLOCKS + 1) * PAD_STRIDE, load16_guarded(g, N, tS + TILE));
-    }
+    if (tid == 0) lds_store16(sb + 48, r.halo);                                  // last 16 bytes of block -1
+    else if (tid == 1) lds_store16(sb + (TILE_BLOCKS + 1) * PAD_STRIDE, r.halo);
+}
+// Copy the tile [tS, tS+TILE) plus HALO bytes on both sides into LDS (zeros outside the corpus).
+__device__ inline void stage_tile(const u8* __restrict__ g, u64 N, u64 tS, u8* sb) {
+    TileRegs r;
+    tile_load(g, N, tS, r);
+    tile_store(r, sb);
 }
 
 __device__ inline PadBlk lane_block(const TileShared& sh, int i) {
@@ -259,26 +364,44 @@ __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, 
 // ---------------------------------------------------------------------------------------------------
 // k_summary: per-tile forward summary (line statistics at the tile edges, record-level alpha flags).
 // ---------------------------------------------------------------------------------------------------
+constexpr int SUM_TPW = 1;   // consecutive tiles per workgroup (the next one is loaded during the current one)
 __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
-                                                 u64 nB, J* __restrict__ SA) {
+                                                 u64 nB, u64 nT, J* __restrict__ SA) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ J wsum[NT / 64];
-    const u64 t = blockIdx.x, tS = t * (u64)TILE;
-    const u64 b = t * (u64)TILE_BLOCKS + threadIdx.x;
-    stage_tile(bytes, N, tS, sh.bytes);
+    const u64 t0 = (u64)blockIdx.x * SUM_TPW;
+    TileRegs regs;
+    tile_load(bytes, N, t0 * (u64)TILE, regs);
+    u64 b = t0 * (u64)TILE_BLOCKS + threadIdx.x;
+    u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
     stage_tables(uni);
-    const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
-    __syncthreads();
-    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs_here, rs_next);
-    J j = lane_J(L.c, L.d);
-    j = wave_reduce_ordered(j, JOp());
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        J acc = wsum[0];
-        for (int w = 1; w < NT / 64; w++) acc = j_combine(acc, wsum[w]);
-        SA[t] = acc;
+#pragma unroll 1
+    for (int i = 0; i < SUM_TPW; i++) {
+        const u64 t = t0 + i;
+        if (t >= nT) break;   // uniform
+        const u64 tS = t * (u64)TILE;
+        tile_store(regs, sh.bytes);
+        const u64 rs_h = rs_here, rs_n = rs_next;
+        __syncthreads();
+        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs_h, rs_n);
+        // the next tile's loads are issued after the register-hungry classification
+        if (i + 1 < SUM_TPW && t + 1 < nT) {
+            tile_load(bytes, N, tS + TILE, regs);
+            b += TILE_BLOCKS;
+            rs_here = b < nB ? rsmap[b] : 0;
+            rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+        }
+        J j = wave_J(lane_J(L.c, L.d));
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            J acc = wsum[0];
+            for (int w = 1; w < NT / 64; w++) acc = j_combine(acc, wsum[w]);
+            SA[t] = acc;
+        }
+        // the next tile_store may overwrite the image: every lane has finished reading it (barrier above);
+        // wsum is rewritten only after the next barrier
     }
 }
 
@@ -963,36 +1086,69 @@ __device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 
     }
 }
 
+// What a workgroup fetches from global memory for one tile; fetched for tile t+1 while tile t is processed.
+struct EmitIn {
+    TileRegs regs;
+    Plan pl;
+    u64 rs, rs_next;      // record-start words of the lane's block and of the next block
+    u64 prev_w, prev_rs;  // lane 0: token bytes / record starts of the block before the tile
+    u64 next_w;           // last lane: token bytes of the block after the tile
+    u64 base;             // scanned output byte / token base of the tile
+};
+template <bool PASSTHROUGH>
+__device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
+                                  const Plan* __restrict__ plan, const u64* __restrict__ tile_base, u64 N, u64 nB,
+                                  u64 t, EmitIn& in) {
+    const int tid = threadIdx.x;
+    const u64 b = t * (u64)TILE_BLOCKS + tid;
+    tile_load(bytes, N, t * (u64)TILE, in.regs);
+    in.rs = b < nB ? rsmap[b] : 0;
+    in.rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    Plan z = {0, 0, 0, 0};
+    in.pl = z;
+    if (!PASSTHROUGH && b < nB) in.pl = plan[b];
+    in.prev_w = in.prev_rs = in.next_w = 0;
+    if (tid == 0 && b > 0) {
+        in.prev_rs = rsmap[b - 1];
+        if (!PASSTHROUGH) in.prev_w = plan[b - 1].TOK & plan[b - 1].C;
+    }
+    if (!PASSTHROUGH && tid == NT - 1 && b + 1 < nB) in.next_w = plan[b + 1].TOK & plan[b + 1].C;
+    in.base = tile_base[t];
+}
+
+constexpr int EMIT_TPW = 4;   // consecutive tiles per workgroup
 template <bool PASSTHROUGH>
 __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
-                                              u64 N, u64 nB, const Plan* __restrict__ plan,
+                                              u64 N, u64 nB, u64 nT, const Plan* __restrict__ plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
                                               u32* __restrict__ tok_start, u32* __restrict__ tok_len,
                                               u64* __restrict__ den_off, u64* __restrict__ tok_off) {
     __shared__ EmitShared sh;
     const int tid = threadIdx.x;
-    const u64 t = blockIdx.x, tS = t * (u64)TILE;
+    const u64 t0 = (u64)blockIdx.x * EMIT_TPW;
+    EmitIn in;
+    emit_fetch<PASSTHROUGH>(bytes, rsmap, plan, tile_base, N, nB, t0, in);
+#pragma unroll 1
+    for (int ti = 0; ti < EMIT_TPW; ti++) {
+    const u64 t = t0 + ti;
+    if (t >= nT) break;   // uniform
+    const u64 tS = t * (u64)TILE;
     const u64 b = t * (u64)TILE_BLOCKS + tid;
-    stage_tile(bytes, N, tS, sh.tile.bytes);
+    tile_store(in.regs, sh.tile.bytes);
     const PadBlk blk = lane_block(sh.tile, tid);
     const u64 p = tS + (u64)tid * BLOCK;
     const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)BLOCK ? (N - p) : (u64)BLOCK);
     const u64 V = below(nvalid);
-    const u64 RS = (b < nB ? rsmap[b] : 0) & V;
-    const bool next_rs = !(p + BLOCK < N) || (rsmap[b + 1] & 1ull);
-    Plan pl = {0, 0, 0, 0};
-    if (!PASSTHROUGH && nvalid > 0) pl = plan[b];
-    // neighbours across the tile edges are fetched by the first and the last lane along with their
-    // own words, so that no lane waits for a memory round trip of its own later
-    u64 prev_w = 0, prev_rs = 0;   // lane 0: token bytes / record starts of the block before the tile
-    bool edge_prev = false, edge_next = false;
-    if (tid == 0 && b > 0) {
-        prev_rs = rsmap[b - 1];
-        if (!PASSTHROUGH) prev_w = plan[b - 1].TOK & plan[b - 1].C;
-    }
-    if (!PASSTHROUGH && tid == NT - 1 && b + 1 < nB) edge_next = (plan[b + 1].TOK & plan[b + 1].C) & 1ull;
+    const u64 RS = in.rs & V;
+    const bool next_rs = !(p + BLOCK < N) || (in.rs_next & 1ull);
+    Plan pl = in.pl;
+    if (nvalid == 0) { Plan z = {0, 0, 0, 0}; pl = z; }
+    const u64 prev_w = in.prev_w, prev_rs = in.prev_rs;
+    bool edge_prev = false, edge_next = (in.next_w & 1ull) != 0;
+    const u64 tb64 = in.base;
     __syncthreads();
+    if (ti + 1 < EMIT_TPW && t + 1 < nT) emit_fetch<PASSTHROUGH>(bytes, rsmap, plan, tile_base, N, nB, t + 1, in);
     if (PASSTHROUGH) {
         Cls c = classify_block_fast(blk, nvalid, dev_tables());
         pl = plan_passthrough(c, V);
@@ -1015,7 +1171,6 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     me.nte = popc(TE);
     me.lts = TS ? tid * BLOCK + top(TS) : -1;
     EmitScan ident = {0, 0, 0, -1};
-    const u64 tb64 = tile_base[t];
     EmitScan seed = {(u32)(tb64 & 0xFFFFFFFFull), (u32)(tb64 >> 32), 0, -1};
     EmitScan tot;
     EmitScan ex = block_scan_excl_fwd(me, EmitOp(), ident, seed, sh.scan, &tot);
@@ -1160,6 +1315,8 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
                 for (u32 i = lo > shift ? lo : shift; i < hi && i < end; i++) denoised[g0 + i] = src[i - lo];
             }
         }
+    }
+    __syncthreads();   // the LDS images are reused by the next tile
     }
 }
 
@@ -1510,7 +1667,8 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
     if (nT) {
         if (!pass) {
             { Prof pr(c, "k_summary");
-              hipLaunchKernelGGL(k_summary, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, SA); }
+              hipLaunchKernelGGL(k_summary, dim3((unsigned)((nT + SUM_TPW - 1) / SUM_TPW)), dim3(NT), 0, st, d_bytes, rsmap, N, nB,
+                                 nT, SA); }
             { Prof pr(c, "k_tile_carry");
               hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)((nT + NT / 64 - 1) / (NT / 64))), dim3(NT), 0, st, SA, nT,
                                  c->seedJ.as<J>(), c->seedS.as<S>()); }
@@ -1537,12 +1695,12 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
           if ((rc = scan_u64(c, c->packed.as<u64>(), nT, tile_base))) return rc; }
         { Prof pr(c, "k_emit");
           if (pass)
-              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, rec_lo, R, N, nB,
-                                 (const Plan*)nullptr, tile_base, (u8*)nullptr, c->tok_start.as<u32>(), c->tok_len.as<u32>(),
+              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes, rsmap,
+                                 d_offsets, rec_lo, R, N, nB, nT, (const Plan*)nullptr, tile_base, (u8*)nullptr, c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off);
           else
-              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, rec_lo, R, N, nB,
-                                 plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
+              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes, rsmap,
+                                 d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off); }
     }
     { Prof pr(c, "k_finish");
@@ -1645,6 +1803,8 @@ int trp_copy_to_host(trp_ctx* c, void* dst, const void* d_src, size_t bytes) {
     return TRP_OK;
 }
 
+}  // extern "C"
+
 // Host result arrays.  Large arrays live in page-locked memory so that the device-to-host copies run
 // at link speed; the blocks are recycled through a process-wide pool (pinning is expensive), small
 // arrays come from malloc.  host_release accepts pointers of either kind.
@@ -1713,6 +1873,8 @@ HostPool& host_pool() {
     return *pool;
 }
 }  // namespace
+
+extern "C" {
 
 void trp_result_free(trp_result* r) {
     if (!r) return;

@@ -21,6 +21,11 @@
 #else
 #define TRP_HD inline
 #endif
+#if defined(__clang__)
+#define TRP_UNROLL _Pragma("unroll")
+#else
+#define TRP_UNROLL
+#endif
 
 namespace trp {
 
@@ -198,38 +203,77 @@ TRP_HD u32 load_u32(const u8* p) {
 // (a & m) | (b & ~m)
 TRP_HD u32 bfi(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }
 
-// 8x8 bit transpose of the bytes of (lo, hi): afterwards byte c of lo (c < 4) / of hi (c - 4) holds
-// bit c of the eight input bytes, input byte r in bit r.
-TRP_HD void transpose8(u32& lo, u32& hi) {
-    u32 t;
-    t = ((lo >> 7) ^ lo) & 0x00AA00AAu; lo = lo ^ t ^ (t << 7);
-    t = ((hi >> 7) ^ hi) & 0x00AA00AAu; hi = hi ^ t ^ (t << 7);
-    t = ((lo >> 14) ^ lo) & 0x0000CCCCu; lo = lo ^ t ^ (t << 14);
-    t = ((hi >> 14) ^ hi) & 0x0000CCCCu; hi = hi ^ t ^ (t << 14);
-    u32 nlo = bfi(0x0F0F0F0Fu, lo, hi << 4);
-    u32 nhi = bfi(0x0F0F0F0Fu, lo >> 4, hi);
-    lo = nlo;
-    hi = nhi;
+// Byte select from the eight bytes {hi:lo}: result byte i is byte sel.byte[i] of the pair, where 0..3
+// name the bytes of lo and 4..7 those of hi.
+TRP_HD u32 byte_perm(u32 hi, u32 lo, u32 sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    u64 pair = ((u64)hi << 32) | lo;
+    u32 r = 0;
+    for (int i = 0; i < 4; i++) r |= (u32)((pair >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+    return r;
+#endif
 }
-// byte `c` of a, b, c2, d packed into one word (a in the low byte)
-TRP_HD u32 gather_byte(u32 a, u32 b, u32 c2, u32 d, int c) {
-    return ((a >> (8 * c)) & 0xFFu) | (((b >> (8 * c)) & 0xFFu) << 8) | (((c2 >> (8 * c)) & 0xFFu) << 16) |
-           (((d >> (8 * c)) & 0xFFu) << 24);
+
+// Transpose the 64 bytes held in w[16] (byte i of the block = byte i%4 of w[i/4]) into the eight bit
+// planes of the byte values: bit i of plane[c] = bit c of byte i.
+// Index algebra: a bit of the input sits at word (i2,i3,i4,i5), in-word position (c0,c1,c2,i0,i1).
+//   1. 4x4 byte transposes among the words that differ in (i3,i4) exchange the byte position with
+//      those two word-index bits: word (i2,i0,i1,i5), position (c0,c1,c2,i3,i4).
+//   2. three rounds of bit exchanges between word pairs swap c0<->i0, c1<->i1, c2<->i2:
+//      word (c2,c0,c1,i5), position (i0,i1,i2,i3,i4) - the natural bit order of a plane half.
+TRP_HD void transpose_block(u32 (&w)[16], u64 (&plane)[8]) {
+TRP_UNROLL
+    for (int base = 0; base < 16; base += 8) {
+TRP_UNROLL
+        for (int k0 = 0; k0 < 2; k0++) {
+            const u32 A = w[base + k0], B = w[base + k0 + 2], C2 = w[base + k0 + 4], D = w[base + k0 + 6];
+            const u32 t0 = byte_perm(B, A, 0x05010400u);    // A0 B0 A1 B1
+            const u32 t1 = byte_perm(B, A, 0x07030602u);    // A2 B2 A3 B3
+            const u32 t2 = byte_perm(D, C2, 0x05010400u);   // C0 D0 C1 D1
+            const u32 t3 = byte_perm(D, C2, 0x07030602u);   // C2 D2 C3 D3
+            w[base + k0] = byte_perm(t2, t0, 0x05040100u);      // A0 B0 C0 D0
+            w[base + k0 + 2] = byte_perm(t2, t0, 0x07060302u);  // A1 B1 C1 D1
+            w[base + k0 + 4] = byte_perm(t3, t1, 0x05040100u);  // A2 B2 C2 D2
+            w[base + k0 + 6] = byte_perm(t3, t1, 0x07060302u);  // A3 B3 C3 D3
+        }
+    }
+TRP_UNROLL
+    for (int k = 0; k < 16; k++) {
+        if (k & 2) continue;   // c0 <-> word bit 1
+        const u32 a = w[k], b = w[k | 2];
+        w[k] = bfi(0x55555555u, a, b << 1);
+        w[k | 2] = bfi(0x55555555u, a >> 1, b);
+    }
+TRP_UNROLL
+    for (int k = 0; k < 16; k++) {
+        if (k & 4) continue;   // c1 <-> word bit 2
+        const u32 a = w[k], b = w[k | 4];
+        w[k] = bfi(0x33333333u, a, b << 2);
+        w[k | 4] = bfi(0x33333333u, a >> 2, b);
+    }
+TRP_UNROLL
+    for (int k = 0; k < 16; k++) {
+        if (k & 1) continue;   // c2 <-> word bit 0
+        const u32 a = w[k], b = w[k | 1];
+        w[k] = bfi(0x0F0F0F0Fu, a, b << 4);
+        w[k | 1] = bfi(0x0F0F0F0Fu, a >> 4, b);
+    }
+TRP_UNROLL
+    for (int c = 0; c < 8; c++) {
+        const int k = ((c >> 2) & 1) | ((c & 1) << 1) | (((c >> 1) & 1) << 2);
+        plane[c] = (u64)w[k] | ((u64)w[k | 8] << 32);
+    }
 }
 
 template <class B>
 TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut) {
-    u32 lo[8], hi[8];
-#pragma unroll
-    for (int g = 0; g < 8; g++) { lo[g] = blk.word(2 * g); hi[g] = blk.word(2 * g + 1); }
-#pragma unroll
-    for (int g = 0; g < 8; g++) transpose8(lo[g], hi[g]);
+    u32 w[16];
+TRP_UNROLL
+    for (int k = 0; k < 16; k++) w[k] = blk.word(k);
     u64 b[8];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        b[c] = (u64)gather_byte(lo[0], lo[1], lo[2], lo[3], c) | ((u64)gather_byte(lo[4], lo[5], lo[6], lo[7], c) << 32);
-        b[c + 4] = (u64)gather_byte(hi[0], hi[1], hi[2], hi[3], c) | ((u64)gather_byte(hi[4], hi[5], hi[6], hi[7], c) << 32);
-    }
+    transpose_block(w, b);
     const u64 V = below(nvalid);
     const u64 n7 = ~b[7] & V;
     const u64 lowq = n7 & ~b[6] & ~b[5] & ~b[4];                 // 0x00-0x0F
