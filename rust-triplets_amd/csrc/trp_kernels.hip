@@ -228,6 +228,181 @@ __device__ inline J wave_J(const J& j) {
     return r;
 }
 
+// ---- line carries of a tile from wave prefix sums and ballots ----------------------------------------
+// What a lane has to know about the blocks around it (LaneCarry) is a segmented sum over the lanes back
+// to the last block with a line start, and forward to the next one.  With x = the part of a block after
+// its last line start (the whole block when it has none) and h = the part before its first line start,
+// both are differences of plain prefix sums over the wave (DPP adds), the flag part of a LineSum and the
+// record-level flags are read off ballots, and only the four wave totals go through LDS.
+
+// Inclusive prefix sum over the 64 lanes of a wave (row shifts inside the 16-lane rows, then the row
+// totals are broadcast into the following rows).
+__device__ inline u32 wave_incl_scan_add(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ inline u32 lane_read(u32 v, int src_lane) {   // any lane reads any lane
+    return (u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+struct FlagBallots { u64 nz, first_pipe, last_pipe, seen; };
+__device__ inline FlagBallots flag_ballots(const LineSum& x) {
+    FlagBallots B = {__ballot(ls_first(x) != 0), __ballot(ls_first(x) == 1u), __ballot(ls_last(x) == 1u),
+                     __ballot(ls_seen_text(x))};
+    return B;
+}
+// f field of the sum of the LineSums of the lanes in m
+__device__ inline u32 flags_of(const FlagBallots& B, u64 m) {
+    const u64 nz = B.nz & m;
+    if (!nz) return 0;
+    const u32 first = ((B.first_pipe >> ctz(nz)) & 1ull) ? 1u : 2u;
+    const u32 last = ((B.last_pipe >> top(nz)) & 1ull) ? 1u : 2u;
+    return first | (last << 2) | ((B.seen & m) ? 16u : 0u);
+}
+__device__ inline LineSum unpack_ls(u32 da, u32 p, u32 f) {
+    LineSum r = {da & 0xFFFFu, da >> 16, p, f};
+    return r;
+}
+
+struct WaveLines {
+    u32 Ix_da, Ix_p, Ih_da, Ih_p;   // inclusive prefix sums over the lanes: x and h, digits | alpha << 16, pipes
+    u32 x_da, x_p;                  // the lane's own x
+    u64 lsm, rsm, gah, gat, c0m, c1m;
+    FlagBallots xb, hb;
+};
+
+__device__ inline WaveLines wave_lines(const J& j) {
+    WaveLines W;
+    const bool has_ls = (j.g & G_LS) != 0;
+    LineSum x;   // field by field: a struct select goes through scratch memory
+    x.d = has_ls ? j.tail.d : j.head.d;
+    x.a = has_ls ? j.tail.a : j.head.a;
+    x.p = has_ls ? j.tail.p : j.head.p;
+    x.f = has_ls ? j.tail.f : j.head.f;
+    W.x_da = x.d | (x.a << 16);
+    W.x_p = x.p;
+    W.Ix_da = wave_incl_scan_add(W.x_da);
+    W.Ix_p = wave_incl_scan_add(W.x_p);
+    W.Ih_da = wave_incl_scan_add(j.head.d | (j.head.a << 16));
+    W.Ih_p = wave_incl_scan_add(j.head.p);
+    W.lsm = __ballot(has_ls);
+    W.rsm = __ballot((j.g & G_RS) != 0);
+    W.gah = __ballot((j.g & G_AH) != 0);
+    W.gat = __ballot((j.g & G_AT) != 0);
+    W.c0m = __ballot((j.g & G_C0) != 0);
+    W.c1m = __ballot((j.g & G_C1) != 0);
+    W.xb = flag_ballots(x);
+    W.hb = flag_ballots(j.head);
+    return W;
+}
+
+// The summary of the whole wave (uniform); equals the ordered fold of j_combine over the lanes.
+__device__ inline J wave_total(const WaveLines& W) {
+    J r;
+    u32 g = 0;
+    if (!W.lsm) {
+        r.head = unpack_ls(readlane_u32(W.Ih_da, 63), readlane_u32(W.Ih_p, 63), flags_of(W.hb, ~0ull));
+        r.tail = ls_empty();
+    } else {
+        const int f = ctz(W.lsm), l = top(W.lsm);
+        r.head = unpack_ls(readlane_u32(W.Ih_da, f), readlane_u32(W.Ih_p, f), flags_of(W.hb, below(f + 1)));
+        const u32 before_da = l > 0 ? readlane_u32(W.Ix_da, l - 1) : 0u, before_p = l > 0 ? readlane_u32(W.Ix_p, l - 1) : 0u;
+        r.tail = unpack_ls(readlane_u32(W.Ix_da, 63) - before_da, readlane_u32(W.Ix_p, 63) - before_p,
+                           flags_of(W.xb, ~below(l)));
+        g |= G_LS;
+        const bool c0l = (W.c0m >> l) & 1ull, c1l = (W.c1m >> l) & 1ull;
+        const u64 rs_before = W.rsm & below(l);
+        bool known;
+        if (rs_before) {
+            const int r0 = top(rs_before);
+            known = ((W.gat >> r0) & 1ull) || (W.gah & below(l) & ~below(r0 + 1)) != 0;
+        } else {
+            known = (W.gah & below(l)) != 0;
+            if (c1l) g |= G_C1;
+        }
+        if (c0l || (c1l && known)) g |= G_C0;
+    }
+    if (!W.rsm) {
+        if (W.gah) g |= G_AH | G_AT;
+    } else {
+        g |= G_RS;
+        if (W.gah & below(ctz(W.rsm) + 1)) g |= G_AH;
+        if (W.gat & ~below(top(W.rsm))) g |= G_AT;
+    }
+    r.g = g;
+    return r;
+}
+
+// Field-wise select on values (a select between two members of one struct would otherwise be turned
+// into an indexed load from a stack copy of the struct).
+__device__ inline u32 sel32(bool c, u32 a, u32 b) {
+    const u32 m = 0u - (u32)c;
+    return (a & m) | (b & ~m);
+}
+__device__ inline LineSum ls_select(bool c, LineSum a, LineSum b) {
+    LineSum r = {sel32(c, a.d, b.d), sel32(c, a.a, b.a), sel32(c, a.p, b.p), sel32(c, a.f, b.f)};
+    return r;
+}
+__device__ inline J j_select(bool c, const J& a, const J& b) {
+    J r;
+    r.head = ls_select(c, a.head, b.head);
+    r.tail = ls_select(c, a.tail, b.tail);
+    r.g = c ? a.g : b.g;
+    return r;
+}
+__device__ inline S s_select(bool c, const S& a, const S& b) {
+    S r;
+    r.head = ls_select(c, a.head, b.head);
+    r.has_ls = c ? a.has_ls : b.has_ls;
+    return r;
+}
+
+// The lane's carries.  Pw = summary of everything before the wave back to the start of the record that
+// covers the wave's first byte, Xw = backward summary of what follows the wave (both uniform).
+__device__ inline LaneCarry wave_carry(const WaveLines& W, const J& Pw, const S& Xw, bool next_rs) {
+    const int L = threadIdx.x & 63;
+    LaneCarry k;
+    const u64 beforeL = below(L);
+    // -- the current line from its start to this block
+    const u64 sb = W.lsm & beforeL;
+    const int s = sb ? top(sb) : 0;
+    const u32 Ex_da = W.Ix_da - W.x_da, Ex_p = W.Ix_p - W.x_p;   // exclusive prefix
+    const u32 at_s_da = lane_read(Ex_da, s), at_s_p = lane_read(Ex_p, s);
+    const bool pw_ar = (Pw.g & G_RS) ? (Pw.g & G_AT) != 0 : (Pw.g & G_AH) != 0;
+    auto ar_at = [&](int n) -> bool {   // the record has an alphabetic char before block n of the wave
+        const u64 bn = below(n);
+        const u64 rb = W.rsm & bn;
+        if (rb) {
+            const int r = top(rb);
+            return ((W.gat >> r) & 1ull) || (W.gah & bn & ~below(r + 1)) != 0;
+        }
+        return pw_ar || (W.gah & bn) != 0;
+    };
+    if (sb) {
+        k.ci = unpack_ls(Ex_da - at_s_da, Ex_p - at_s_p, flags_of(W.xb, beforeL & ~below(s)));
+        k.ci_rab = ((W.c0m >> s) & 1ull) || (((W.c1m >> s) & 1ull) && ar_at(s));
+    } else {
+        const LineSum own = unpack_ls(Ex_da, Ex_p, flags_of(W.xb, beforeL));
+        k.ci = ls_add(ls_select((Pw.g & G_LS) != 0, Pw.tail, Pw.head), own);
+        k.ci_rab = (Pw.g & G_C0) != 0;
+    }
+    k.ar_in = ar_at(L);
+    // -- the rest of the block's last line after this block
+    const u64 afterL = ~below(L + 1);
+    const u64 eb = W.lsm & afterL;
+    const int e = eb ? ctz(eb) : 63;
+    const u32 at_e_da = lane_read(W.Ih_da, e), at_e_p = lane_read(W.Ih_p, e);
+    const LineSum fwd = unpack_ls(at_e_da - W.Ih_da, at_e_p - W.Ih_p, flags_of(W.hb, afterL & below(e + 1)));
+    k.co = eb ? fwd : ls_add(fwd, Xw.head);
+    k.next_rs = next_rs;
+    return k;
+}
+
 struct JOp { __device__ J operator()(const J& a, const J& b) const { return j_combine(a, b); } };
 struct SOp { __device__ S operator()(const S& a, const S& b) const { return s_combine(a, b); } };
 
@@ -618,7 +793,8 @@ struct U32Add { __device__ u32 operator()(u32 a, u32 b) const { return a + b; } 
 struct PlanShared {
     TileShared tile;   // byte image; after classification reused for the eight G3Masks arrays
     J jscan[NT / 64];
-    S sscan[NT / 64];
+    J seed_j;
+    S seed_s;
     u64 tokc[TILE_BLOCKS];
     u64 marks[TILE_BLOCKS];
     uint16_t list[G3_LCAP];
@@ -633,7 +809,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
                                               Plan* __restrict__ plan, u64* __restrict__ g3m,
                                               u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
-                                              u32* __restrict__ tile_flags, u32* __restrict__ tile_marks) {
+                                              u32* __restrict__ tile_flags, u32* __restrict__ tile_marks, u32 stop_after) {
     __shared__ PlanShared sh;
     __shared__ UniShared uni;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -642,17 +818,34 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     stage_tile(bytes, N, tS, sh.tile.bytes);
     stage_tables(uni);
     const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
-    const J sJ = seedJ[t];
-    const S sS = seedS[t];
+    if (tid == 0) sh.seed_j = seedJ[t];
+    if (tid == 64) sh.seed_s = seedS[t];
     __syncthreads();
+    if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
     LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, rs_here, rs_next);
-    J j = lane_J(L.c, L.d);
-    J P = block_scan_excl_fwd(j, JOp(), j_identity(), sJ, sh.jscan, (J*)nullptr);
-    S X = block_scan_excl_bwd(s_from_J(j), SOp(), s_identity(), sS, sh.sscan);
-    LaneCarry k = carry_from(P, X, L.next_rs);
+    if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3m[b] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
+    const WaveLines W = wave_lines(lane_J(L.c, L.d));
+    {
+        const J wt = wave_total(W);
+        if (lane == 0) sh.jscan[wave] = wt;
+    }
+    __syncthreads();   // also: every lane has classified its block, the byte image is free from here on
+    // what enters this wave from the left and from the right: folds over the other waves' totals, written
+    // out for the four waves and selected field by field (keeps the summaries in registers)
+    J Pw = sh.seed_j;
+    S Xw = sh.seed_s;
+#pragma unroll
+    for (int w = 0; w < NT / 64 - 1; w++) {
+        Pw = j_select(w < wave, j_combine(Pw, sh.jscan[w]), Pw);
+        const int v = NT / 64 - 1 - w;
+        Xw = s_select(v > wave, s_combine(s_from_J(sh.jscan[v]), Xw), Xw);
+    }
+    LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
+    if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3m[b] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
     Plan pl = plan_block(L.c, L.d, k, cfg);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
+    if (stop_after == 4) { if (pl.C == 0x123456789ull) g3m[b] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
     u64 marks = pl.TOK & ~pl.C;
     pl.TOK &= pl.C;
     {
@@ -693,7 +886,9 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
             marks = left;
         }
     }
+    if (stop_after == 5) { if (pl.C == 0x123456789ull) g3m[b] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }
     if (L.nvalid > 0) { plan[b] = pl; g3m[b] = marks; }
+    if (stop_after == 6) return;
     u64 TOKC = pl.TOK;
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
     sh.tokc[tid] = TOKC;
@@ -1041,6 +1236,8 @@ struct EmitOp {
     }
 };
 
+struct Pair32 { u32 lo, hi; };   // two consecutive dwords at a 4-byte aligned address
+
 struct EmitShared {
     TileShared tile;
     alignas(16) u8 out[TILE + 64];   // output image of the tile (linear)
@@ -1123,7 +1320,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
                                               u64 N, u64 nB, u64 nT, const Plan* __restrict__ plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
                                               u32* __restrict__ tok_start, u32* __restrict__ tok_len,
-                                              u64* __restrict__ den_off, u64* __restrict__ tok_off) {
+                                              u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
     __shared__ EmitShared sh;
     const int tid = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * EMIT_TPW;
@@ -1149,6 +1346,8 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     const u64 tb64 = in.base;
     __syncthreads();
     if (ti + 1 < EMIT_TPW && t + 1 < nT) emit_fetch<PASSTHROUGH>(bytes, rsmap, plan, tile_base, N, nB, t + 1, in);
+    // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every tile after that phase
+    if (stop_after == 1) { __syncthreads(); continue; }
     if (PASSTHROUGH) {
         Cls c = classify_block_fast(blk, nvalid, dev_tables());
         pl = plan_passthrough(c, V);
@@ -1208,12 +1407,12 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
             }
         }
     }
+    if (stop_after == 2) { __syncthreads(); continue; }
     // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes
     // with no separator inside; its source is contiguous in the lane's block and its destination is
     // contiguous in the output image, so it moves as (unaligned source, aligned destination) dwords.
     // Lanes start their runs at different dwords so that the stride-64 pattern spreads over the banks.
     if (!PASSTHROUGH) {
-        typedef u32 __attribute__((aligned(1))) u32u;
         const u8* src0 = blk.p;
         u32 o = ex.nb - out0 + shift;
         u64 Cm = pl.C;
@@ -1233,16 +1432,22 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
             for (u32 i = 0; i < head; i++) dst[i] = src[i];
             const u32 nd = (len - head) >> 2;
             const u32 rot = (lrot * nd) >> 4;
+            // destination dwords are aligned; the source is read as aligned dword pairs and shifted in
+            // registers (LDS accesses that straddle a dword stall the whole LDS pipeline)
+            const u32 sa = (u32)(a0 + head) & 3u;            // the block itself is dword aligned
+            const u8* sbase = src + head - sa;
             for (u32 q = 0; q < nd; q++) {
                 u32 k = q + rot;
                 if (k >= nd) k -= nd;
-                *reinterpret_cast<u32*>(dst + head + 4 * k) = *reinterpret_cast<const u32u*>(src + head + 4 * k);
+                const Pair32 w = *reinterpret_cast<const Pair32*>(sbase + 4 * k);
+                *reinterpret_cast<u32*>(dst + head + 4 * k) = __builtin_amdgcn_alignbyte(w.hi, w.lo, sa);
             }
             for (u32 i = head + 4 * nd; i < len; i++) dst[i] = src[i];
             o += len;
         }
     }
     __syncthreads();
+    if (stop_after == 3) { __syncthreads(); continue; }
     // tokens: one (start, len) record per token end.  Tokens that start and end inside the tile are
     // staged in LDS (the input image is no longer needed) and stored with coalesced writes below.
     u32* tokstage = reinterpret_cast<u32*>(sh.tile.bytes);
@@ -1289,6 +1494,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
             tok_len[tok0 + i] = v >> 16;
         }
     }
+    if (stop_after == 4) { __syncthreads(); continue; }
     // per-record offsets
     {
         u32 r0 = rec_lo[t], r1 = rec_lo[t + 1];
@@ -1301,6 +1507,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
             tok_off[r] = (u64)(sh.tb[l] + popc(sh.ts[l] & lowm));
         }
     }
+    if (stop_after == 5) { __syncthreads(); continue; }
     // LDS output image -> global, 16-byte stores where the destination is aligned
     if (!PASSTHROUGH) {
         const u32 n = sh.total.nb - out0;   // bytes this tile emits
@@ -1475,6 +1682,19 @@ struct trp_ctx {
     trp_result last = {};
     u64 last_R = 0;
     bool have_last = false;
+    // Profiling aid: with profiling on and TRP_PROFILE_EMIT_STOP=k (1..5) in the environment, k_emit ends
+    // every tile after phase k, so that the phases can be timed one by one.  The results of such a call
+    // are incomplete; calls without profiling are never affected.
+    u32 plan_stop() const {   // the same for k_plan (TRP_PROFILE_PLAN_STOP=1..6)
+        if (!profiling) return 0;
+        const char* e = getenv("TRP_PROFILE_PLAN_STOP");
+        return e ? (u32)atoi(e) : 0u;
+    }
+    u32 emit_stop() const {
+        if (!profiling) return 0;
+        const char* e = getenv("TRP_PROFILE_EMIT_STOP");
+        return e ? (u32)atoi(e) : 0u;
+    }
 };
 
 namespace {
@@ -1675,7 +1895,7 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
             { Prof pr(c, "k_plan");
               hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, c->seedJ.as<J>(),
                                  c->seedS.as<S>(), dc, plan, c->g3m.as<u64>(), tbytes, ttoks, tflags,
-                                 c->tile_marks.as<u32>()); }
+                                 c->tile_marks.as<u32>(), c->plan_stop()); }
             { Prof pr(c, "k_gate3");
               hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, c->tile_marks.as<u32>(), nT,
                                  c->marks64.as<u64>());
@@ -1697,11 +1917,11 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
           if (pass)
               hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes, rsmap,
                                  d_offsets, rec_lo, R, N, nB, nT, (const Plan*)nullptr, tile_base, (u8*)nullptr, c->tok_start.as<u32>(), c->tok_len.as<u32>(),
-                                 den_off, tok_off);
+                                 den_off, tok_off, c->emit_stop());
           else
               hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes, rsmap,
                                  d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
-                                 den_off, tok_off); }
+                                 den_off, tok_off, c->emit_stop()); }
     }
     { Prof pr(c, "k_finish");
       // all records at/after N (at least the sentinel entry R)
