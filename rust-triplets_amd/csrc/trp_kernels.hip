@@ -5,13 +5,14 @@
 //   rec_lo[nT+2]                  first record that starts at/after each tile start (+ one for N)
 //   SA[nT]                        per-tile forward summary (struct J) written by k_summary
 //   plan[nB] (4 x u64)            emit plan bit planes (struct Plan) written by k_plan / k_gate3
-//   g3m[nB]                       first bytes of the digit-heavy lines k_gate3 has to solve
+//   g3list[]                      digit-heavy lines that k_plan could not solve inside a tile (position | flags)
 //   tile_bytes[nT], tile_toks[nT], tile_flags[nT]   emitted bytes / token starts per tile
 //   tile_base[nT+1]               exclusive prefix of (bytes | toks<<32)
 //   denoised[D], tok_start[T], tok_len[T], *_offsets[R+1], chunks[C]   results
 //
 // Kernel sequence with the denoiser enabled:
-//   k_rec_lo -> k_summary -> k_plan -> k_gate3 -> k_pack_tiles -> scan(3) -> k_emit -> k_finish
+//   k_rec_lo, k_rsmap -> k_summary -> k_tile_carry -> k_plan -> k_gate3_solve -> k_pack_tiles -> scan(3) -> k_emit
+//   -> k_finish
 //   -> k_chunk_count -> scan(3) -> k_chunk_emit
 // and with it disabled: k_rec_lo -> k_count_tokens -> k_pack_tiles -> scan(3) -> k_emit<passthrough> ...
 //
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, co
             rs_here = b < nB ? rsmap[b] : 0;
             rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
         }
-        J j = wave_J(lane_J(L.c, L.d));
+        J j = wave_total(wave_lines(lane_J(L.c, L.d)));
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -801,15 +802,17 @@ struct PlanShared {
     G3Tok tok[NT / 64][G3_MAXT];
     u32 scan32[NT / 64];
     u32 nlist;
+    u64 g3base;
     u32 red[3][NT / 64];
 };
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 
 __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
-                                              Plan* __restrict__ plan, u64* __restrict__ g3m,
+                                              Plan* __restrict__ plan, u64* __restrict__ g3list, u64 g3cap,
+                                              u64* __restrict__ g3count,
                                               u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
-                                              u32* __restrict__ tile_flags, u32* __restrict__ tile_marks, u32 stop_after) {
+                                              u32* __restrict__ tile_flags, u32 stop_after) {
     __shared__ PlanShared sh;
     __shared__ UniShared uni;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
     LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, rs_here, rs_next);
-    if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3m[b] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
+    if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
     const WaveLines W = wave_lines(lane_J(L.c, L.d));
     {
         const J wt = wave_total(W);
@@ -841,11 +844,11 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
         Xw = s_select(v > wave, s_combine(s_from_J(sh.jscan[v]), Xw), Xw);
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
-    if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3m[b] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
+    if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
     Plan pl = plan_block(L.c, L.d, k, cfg);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
-    if (stop_after == 4) { if (pl.C == 0x123456789ull) g3m[b] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
+    if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
     u64 marks = pl.TOK & ~pl.C;
     pl.TOK &= pl.C;
     {
@@ -886,8 +889,8 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
             marks = left;
         }
     }
-    if (stop_after == 5) { if (pl.C == 0x123456789ull) g3m[b] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }
-    if (L.nvalid > 0) { plan[b] = pl; g3m[b] = marks; }
+    if (stop_after == 5) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }
+    if (L.nvalid > 0) plan[b] = pl;
     if (stop_after == 6) return;
     u64 TOKC = pl.TOK;
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
@@ -905,20 +908,30 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     }
     if (lane == 0) { sh.red[0][wave] = nb; sh.red[1][wave] = ntk; sh.red[2][wave] = nmk; }
     __syncthreads();
+    u32 sm = 0;
+    for (int w = 0; w < NT / 64; w++) sm += sh.red[2][w];
     if (tid == 0) {
-        u32 sb = 0, st = 0, sm = 0;
-        for (int w = 0; w < NT / 64; w++) { sb += sh.red[0][w]; st += sh.red[1][w]; sm += sh.red[2][w]; }
+        u32 sb = 0, st = 0;
+        for (int w = 0; w < NT / 64; w++) { sb += sh.red[0][w]; st += sh.red[1][w]; }
         tile_bytes[t] = sb;
         tile_toks[t] = st;
-        tile_marks[t] = sm;
         u32 f = 0;
         if ((sh.tokc[0] & 1ull) && !(L.d.LS & 1ull)) f |= TF_FIRST_CONT;   // thread 0's own block
         if (sh.tokc[TILE_BLOCKS - 1] >> 63) f |= TF_LAST_TOK;
         tile_flags[t] = f;
     }
+    if (sm > 0) {   // uniform, rare: lines left for k_gate3_solve go to the global work list
+        if (tid == 0) sh.g3base = atomicAdd(reinterpret_cast<unsigned long long*>(g3count), (unsigned long long)sm);
+        u32 at = block_scan_excl_fwd((u32)popc(marks), U32Add(), 0u, 0u, sh.scan32, (u32*)nullptr);   // barriers inside
+        u64 pos = sh.g3base + at;
+        for (u64 m = marks; m; m &= m - 1, pos++) {
+            const int jb = ctz(m);
+            if (pos < g3cap)
+                g3list[pos] = (b * 64 + (u64)jb) | (((pl.PSP >> jb) & 1ull) << 32) | (((pl.PNL >> jb) & 1ull) << 33);
+        }
+    }
 }
 
-// Pass-through configuration: token starts per tile (no denoising, the text stays in place).
 __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
                                                       u64 nB, u32* __restrict__ tile_bytes,
                                                       u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
@@ -964,41 +977,6 @@ __device__ inline void plan_or(Plan* plan, u64 word, u64 c, u64 tok, u64 psp, u6
     if (tok) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].TOK), tok);
     if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PSP), psp);
     if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PNL), pnl);
-}
-
-// Marked lines -> compact work list (entry = position | table << 32 | rab << 33).  mark_base is the
-// exclusive prefix of the per-tile mark counts.
-__global__ __launch_bounds__(NT) void k_gate3_collect(const u64* __restrict__ g3m, const Plan* __restrict__ plan,
-                                                       u64 nB, const u64* __restrict__ mark_base, u64 cap,
-                                                       u64* __restrict__ list) {
-    __shared__ u32 wsum[NT / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 t = blockIdx.x;
-    const u64 nm = mark_base[t + 1] - mark_base[t];
-    if (nm == 0) return;
-    const u64 b = t * (u64)TILE_BLOCKS + tid;
-    u64 marks = b < nB ? g3m[b] : 0;
-    u32 cnt = popc(marks), inc = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        u32 o = (u32)__shfl_up((int)inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    u32 pre = 0;
-    for (int w = 0; w < wave; w++) pre += wsum[w];
-    u64 at = mark_base[t] + pre + inc - cnt;
-    if (marks) {
-        // flag bits at a marked position are only ever changed by the lane that solves that line
-        u64 pspw = plan[b].PSP, pnlw = plan[b].PNL;
-        while (marks) {
-            int jb = ctz(marks);
-            marks &= marks - 1;
-            if (at < cap) list[at] = (b * 64 + jb) | (((pspw >> jb) & 1ull) << 32) | (((pnlw >> jb) & 1ull) << 33);
-            at++;
-        }
-    }
 }
 
 // Guarded view of a block of the corpus in global memory (zeros outside [0, n)).
@@ -1203,10 +1181,6 @@ __global__ __launch_bounds__(NT) void k_scan_final(const u64* __restrict__ in, u
 
 // tile counts -> packed u64 (bytes | toks << 32); a token that continues across a tile edge was
 // counted as a start by the right-hand tile: take it back here.
-__global__ void k_widen_u32(const u32* __restrict__ in, u64 n, u64* __restrict__ out) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
-}
 
 __global__ void k_pack_tiles(const u32* __restrict__ tile_bytes, const u32* __restrict__ tile_toks,
                              const u32* __restrict__ tile_flags, u64 nT, u64* __restrict__ packed) {
@@ -1670,7 +1644,7 @@ struct DevBuf {
 struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf rec_lo, rsmap, SA, seedJ, seedS, plan, g3m, tile_marks, marks64, mark_base, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
+    DevBuf rec_lo, rsmap, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
@@ -1788,8 +1762,8 @@ void trp_destroy(trp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->rec_lo, &c->rsmap, &c->SA, &c->seedJ, &c->seedS, &c->plan, &c->g3m, &c->tile_marks,
-                      &c->marks64, &c->mark_base, &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
+    DevBuf* bufs[] = {&c->rec_lo, &c->rsmap, &c->SA, &c->seedJ, &c->seedS, &c->plan,
+                      &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
                       &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len};
@@ -1857,13 +1831,9 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
     if (!pass) {
         if ((rc = c->SA.ensure((nT + 1) * sizeof(J)))) return rc;
         if ((rc = c->plan.ensure((nB + 1) * sizeof(Plan)))) return rc;
-        if ((rc = c->g3m.ensure((nB + 1) * sizeof(u64)))) return rc;
         if ((rc = c->denoised.ensure(N + 64))) return rc;
         if ((rc = c->seedJ.ensure((nT + 1) * sizeof(J)))) return rc;
         if ((rc = c->seedS.ensure((nT + 1) * sizeof(S)))) return rc;
-        if ((rc = c->tile_marks.ensure((nT + 1) * sizeof(u32)))) return rc;
-        if ((rc = c->marks64.ensure((nT + 1) * sizeof(u64)))) return rc;
-        if ((rc = c->mark_base.ensure((nT + 2) * sizeof(u64)))) return rc;
         if ((rc = c->g3list.ensure(g3_cap * sizeof(u64)))) return rc;
     }
     hipStream_t st = c->stream;
@@ -1894,16 +1864,11 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
                                  c->seedJ.as<J>(), c->seedS.as<S>()); }
             { Prof pr(c, "k_plan");
               hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, c->seedJ.as<J>(),
-                                 c->seedS.as<S>(), dc, plan, c->g3m.as<u64>(), tbytes, ttoks, tflags,
-                                 c->tile_marks.as<u32>(), c->plan_stop()); }
+                                 c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes, ttoks, tflags,
+                                 c->plan_stop()); }
             { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, c->tile_marks.as<u32>(), nT,
-                                 c->marks64.as<u64>());
-              if ((rc = scan_u64(c, c->marks64.as<u64>(), nT, c->mark_base.as<u64>()))) return rc;
-              hipLaunchKernelGGL(k_gate3_collect, dim3((unsigned)nT), dim3(NT), 0, st, c->g3m.as<u64>(), plan, nB,
-                                 c->mark_base.as<u64>(), g3_cap, c->g3list.as<u64>());
               hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, R, N, nB, dc, plan,
-                                 c->g3list.as<u64>(), c->mark_base.as<u64>() + nT, g3_cap, tbytes, ttoks, totals); }
+                                 c->g3list.as<u64>(), totals + 6, g3_cap, tbytes, ttoks, totals); }
         } else {
             Prof pr(c, "k_count_tokens");
             hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, tbytes, ttoks,
