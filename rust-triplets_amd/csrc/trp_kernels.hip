@@ -642,7 +642,6 @@ constexpr u32 G3_LCAP = 1024;   // lines per tile that can be listed in LDS
 constexpr u32 G3_MAXW = 4;      // a line may touch at most this many 64-byte blocks ...
 constexpr u32 G3_MAXT = 64;     // ... and hold at most this many tokens; longer lines go to k_gate3_solve
 
-struct G3Tok { u32 ts, te, dig, alp; };
 
 // Per-block masks of the tile, kept in the LDS region of the (no longer needed) byte image.
 struct G3Masks {
@@ -650,24 +649,20 @@ struct G3Masks {
     u64 *G, *gPSP, *gPNL;              // outputs: kept token bytes, ' ' / '\n' separators
 };
 
-// Sum of v over the lanes where pred holds, from ballots of the bit planes of v (no cross-lane data
-// movement; v is small here: digits or letters of one token).
-__device__ inline u32 wave_masked_sum(bool pred, u32 v) {
-    u32 sum = 0;
-    for (int bpl = 0; bpl < 32; bpl++) {
-        if (!__ballot(pred && (v >> bpl) != 0)) break;
-        sum += (u32)popc(__ballot(pred && ((v >> bpl) & 1u))) << bpl;
-    }
-    return sum;
-}
-
-// Solves one digit-heavy line (gate 3, reference strip_digit_tokens) with the 64 lanes of a wave: lane
-// t owns token t.  Returns false when the line does not fit (left to the serial kernel).
+// Solves one digit-heavy line (gate 3, reference strip_digit_tokens, denoiser_preprocessor.rs:70-140) with
+// the 64 lanes of a wave.  Returns false when the line does not fit (left to the serial solver).
 // The mask arrays are indexed by block number within a view of n_words blocks; s is the position of
 // the line's first byte in the view and corpus_end the position where the corpus ends (or ~0 when that
 // is outside the view).
+//   1. token starts of the line's (at most four) blocks; the lane whose index is the bit position of a
+//      start counts the digits and letters of that token and files them under the token's number;
+//   2. in token space (bit t = token t) everything is wave-uniform mask algebra: the seed set is the
+//      tokens with a letter, wave k the not yet kept neighbours of the kept set, sums are popcounts over
+//      the ballots of the bit planes of the per-token counts;
+//   3. back in byte space the kept tokens are the runs of token bytes whose start bit is kept
+//      (runs & ~(runs + kept_starts), with the carry passed from block to block).
 __device__ inline bool g3_wave_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
-                                     float max_ratio, G3Tok* tb, u64* kept_mask_out) {
+                                     float max_ratio, u32* tb) {
     const int lane = threadIdx.x & 63;
     const u32 w0 = s >> 6;
     // end of the line: the next line start, or the end of the corpus
@@ -707,85 +702,213 @@ __device__ inline bool g3_wave_solve(const G3Masks& a, u32 s, bool table, bool r
     }
     const u32 nt = pre[G3_MAXW];
     if (nt == 0 || nt > G3_MAXT) return false;
-    // the lane whose index equals the bit position of a token start measures that token
+    // 1. per-token digit / letter counts, filed by token number
+    u32 my_t[G3_MAXW];
 #pragma unroll
     for (u32 j = 0; j < G3_MAXW; j++) {
+        my_t[j] = 0xFFFFFFFFu;
         if ((TS[j] >> lane) & 1ull) {
             const u32 t = pre[j] + (u32)popc(TS[j] & below(lane));
-            G3Tok k;
-            k.ts = (w0 + j) * 64u + (u32)lane;
+            my_t[j] = t;
             const u64 from = ~below(lane);
             const u64 stop = ~X[j] & from;
+            u32 dig, alp;
             if (stop) {
-                const int eb = ctz(stop);
-                const u64 r = from & below(eb);
-                k.dig = popc(DG[j] & r);
-                k.alp = popc(AL[j] & r);
-                k.te = (w0 + j) * 64u + (u32)eb;
+                const u64 r = from & below(ctz(stop));
+                dig = popc(DG[j] & r);
+                alp = popc(AL[j] & r);
             } else {
-                k.dig = popc(DG[j] & from);
-                k.alp = popc(AL[j] & from);
-                k.te = (w0 + nw) * 64u;
+                dig = popc(DG[j] & from);
+                alp = popc(AL[j] & from);
                 bool done = false;
 #pragma unroll
                 for (u32 j2 = j + 1; j2 < G3_MAXW; j2++) {
                     if (!done && j2 < nw) {
                         const u64 stop2 = ~X[j2];
-                        if (stop2) {
-                            const int eb = ctz(stop2);
-                            k.dig += popc(DG[j2] & below(eb));
-                            k.alp += popc(AL[j2] & below(eb));
-                            k.te = (w0 + j2) * 64u + (u32)eb;
-                            done = true;
-                        } else {
-                            k.dig += popc(DG[j2]);
-                            k.alp += popc(AL[j2]);
-                        }
+                        const u64 r2 = stop2 ? below(ctz(stop2)) : ~0ull;
+                        dig += popc(DG[j2] & r2);
+                        alp += popc(AL[j2] & r2);
+                        done = stop2 != 0;
                     }
                 }
             }
-            tb[t] = k;
+            tb[t] = dig | (alp << 16);
         }
     }
     __threadfence_block();
-    G3Tok tk = {0, 0, 0, 0};
-    const bool have = (u32)lane < nt;
-    if (have) tk = tb[lane];
-    const bool isalpha = have && tk.alp > 0;
-    const u64 A = __ballot(isalpha);
-    u32 dist = 0xFFFFFFFFu;
-    if (isalpha) dist = 0;
-    else if (have) {
-        const u64 pa = A & below(lane), na = A & ~below(lane + 1);
-        const u32 df = pa ? (u32)(lane - top(pa)) : 0xFFFFFFFFu;
-        const u32 db = na ? (u32)(ctz(na) - lane) : 0xFFFFFFFFu;
-        dist = df < db ? df : db;
+    const u32 mine = (u32)lane < nt ? tb[lane] : 0u;
+    const u32 dig = mine & 0xFFFFu, alp = mine >> 16;
+    // 2. token space
+    const u64 valid = below((int)nt);
+    const u64 A = __ballot(alp > 0);
+    u64 pd[9], pa[9];   // a token has at most 256 bytes
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        pd[k] = __ballot((dig >> k) & 1u);
+        pa[k] = __ballot((alp >> k) & 1u);
     }
-    u64 d0 = wave_masked_sum(isalpha, tk.dig), a0 = wave_masked_sum(isalpha, tk.alp);
-    u32 K = 0;
-    for (u32 k = 1; k <= G3_MAXT; k++) {
-        const bool in_wave = have && dist == k;
-        if (!__ballot(in_wave)) break;
-        const u64 wd = wave_masked_sum(in_wave, tk.dig);
+    u64 d0 = 0, a0 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        d0 += (u64)popc(pd[k] & A) << k;
+        a0 += (u64)popc(pa[k] & A) << k;
+    }
+    u64 kept = A;
+    while (true) {
+        const u64 next = (kept | (kept << 1) | (kept >> 1)) & valid;
+        const u64 wave_k = next & ~kept;
+        if (!wave_k) break;
+        u64 wd = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) wd += (u64)popc(pd[k] & wave_k) << k;
         if (ratio_exceeds64(d0 + wd, a0, max_ratio)) break;
         d0 += wd;
-        K = k;
+        kept = next;
     }
-    const bool keep = have && (isalpha || dist <= K);
-    const u64 km = __ballot(keep);
-    if (kept_mask_out) *kept_mask_out = km;
-    if (keep) {
-        const bool first = lane == ctz(km);
-        const u32 ww0 = tk.ts >> 6, ww1 = (tk.te - 1u) >> 6;
-        for (u32 w = ww0; w <= ww1; w++) {
-            const u32 lo_b = w == ww0 ? (tk.ts & 63u) : 0u;
-            const u32 hi_b = w == ww1 ? ((tk.te - 1u) & 63u) + 1u : 64u;
-            atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w]), below((int)hi_b) & ~below((int)lo_b));
+    // 3. byte space: kept starts per block, then the runs they start
+    u64 first_pending = 1;   // the first kept token gets the line-break flag, the others a space
+    u64 cin = 0;
+#pragma unroll
+    for (u32 j = 0; j < G3_MAXW; j++) {
+        if (j < nw) {
+            const bool k_here = my_t[j] != 0xFFFFFFFFu && ((kept >> my_t[j]) & 1ull);
+            const u64 ks = __ballot(k_here);   // kept token starts of block j
+            const u64 t1 = X[j] + ks, sum = t1 + cin;
+            const u64 g = X[j] & ~sum;
+            cin = (t1 < ks || sum < t1) ? 1ull : 0ull;   // carry out: a kept run reaches the next block
+            u64 psp = ks, pnl = 0;
+            if (first_pending && ks) {
+                const u64 low = ks & (0ull - ks);
+                psp = ks & ~low;
+                if (rab) pnl = low;
+                first_pending = 0;
+            }
+            if (lane == 0) {
+                if (g) atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w0 + j]), g);
+                if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[w0 + j]), psp);
+                if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[w0 + j]), pnl);
+            }
         }
-        const u64 pb = 1ull << (tk.ts & 63u);
-        if (!first) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[ww0]), pb);
-        else if (rab) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[ww0]), pb);
     }
+    return true;
+}
+
+// The same solver run by a single lane (one line per lane, 64 lines per wave at a time): two serial
+// walks over the line's tokens on the block masks, with the expansion in between done as mask algebra
+// in token space (bit t = token t).  Used inside k_plan where a tile holds dozens of short digit-heavy
+// lines.  Returns false when the line does not fit (more than G3_MAXW blocks or 64 tokens).
+struct G3Walk {
+    const G3Masks& a;
+    u32 w0, w1, s, e;
+    bool table;
+    __device__ u64 range(u32 w) const {
+        u64 r = ~0ull;
+        if (w == w0) r &= ~below((int)(s & 63u));
+        if (w == w1 && (e & 63u)) r &= below((int)(e & 63u));
+        return r;
+    }
+    __device__ u64 runs(u32 w) const { return ~(a.ws[w] | (table ? a.pipe[w] : 0ull)) & range(w); }
+    // Calls f(w, mask, first_part, last_part) for every piece of every token, in order: a token is one
+    // piece unless it crosses a block edge.
+    template <class F>
+    __device__ void for_each_piece(F f) const {
+        bool open = false;
+        for (u32 w = w0; w <= w1; w++) {
+            u64 x = runs(w);
+            if (open && !(x & 1ull)) { f(w, 0ull, false, true); open = false; }   // ended at the block edge
+            while (x) {
+                const int p = ctz(x);
+                const u64 r = ~x >> p;
+                const int len = r ? ctz(r) : 64 - p;
+                const u64 m = (len == 64 ? ~0ull : (below(len) << p));
+                const bool reaches_edge = p + len == 64 && w < w1;
+                f(w, m, !open, !reaches_edge);
+                open = reaches_edge;
+                x &= ~m;
+                if (reaches_edge) break;
+            }
+        }
+        if (open) f(w1, 0ull, false, true);
+    }
+};
+
+__device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
+                                     float max_ratio) {
+    const u32 w0 = s >> 6;
+    u32 e = 0xFFFFFFFFu;
+    for (u32 w = w0; w <= w0 + G3_MAXW && w < n_words; w++) {
+        u64 m = a.ls[w];
+        if (w == w0) m &= ~below((int)(s & 63u) + 1);
+        if (m) { e = w * 64u + (u32)ctz(m); break; }
+    }
+    if (e == 0xFFFFFFFFu) {
+        if (corpus_end != 0xFFFFFFFFu && corpus_end <= (w0 + G3_MAXW) * 64u) e = corpus_end;
+        else return false;
+    }
+    const u32 w1 = (e - 1u) >> 6;
+    if (w1 - w0 >= G3_MAXW) return false;
+    const G3Walk walk = {a, w0, w1, s, e, table};
+    // walk 1: per-token digit counts as bit planes over token numbers, tokens with a letter, letters in all
+    u64 A = 0, pd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 nt = 0, dig = 0, alp = 0, a0 = 0;
+    walk.for_each_piece([&](u32 w, u64 m, bool first_part, bool last_part) {
+        if (first_part) { dig = 0; alp = 0; }
+        dig += (u32)popc(a.dig[w] & m);
+        alp += (u32)popc(a.alp[w] & m);
+        if (last_part) {
+            if (nt < 64) {
+                if (alp) A |= 1ull << nt;
+#pragma unroll
+                for (int k = 0; k < 8; k++) pd[k] |= (u64)((dig >> k) & 1u) << nt;
+            }
+            a0 += alp;
+            nt++;
+        }
+    });
+    if (nt == 0 || nt > 64) return false;
+    // expansion (denoiser_preprocessor.rs:94-131)
+    const u64 valid = below((int)nt);
+    u64 d0 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d0 += (u64)popc(pd[k] & A) << k;
+    u64 kept = A;
+    while (true) {
+        const u64 next = (kept | (kept << 1) | (kept >> 1)) & valid;
+        const u64 wave_k = next & ~kept;
+        if (!wave_k) break;
+        u64 wd = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) wd += (u64)popc(pd[k] & wave_k) << k;
+        if (ratio_exceeds64(d0 + wd, (u64)a0, max_ratio)) break;
+        d0 += wd;
+        kept = next;
+    }
+    // walk 2: the bytes of the kept tokens, a separator flag at the start of each
+    u32 t = 0;
+    bool first_kept = true, keep = false;
+    u64 g = 0, psp = 0, pnl = 0;
+    u32 cur_w = w0;
+    auto flush = [&](u32 w) {
+        if (g) atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w]), g);
+        if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[w]), psp);
+        if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[w]), pnl);
+        g = psp = pnl = 0;
+    };
+    walk.for_each_piece([&](u32 w, u64 m, bool first_part, bool last_part) {
+        if (w != cur_w) { flush(cur_w); cur_w = w; }
+        if (first_part) {
+            keep = (kept >> t) & 1ull;
+            if (keep) {
+                const u64 low = m & (0ull - m);
+                if (!first_kept) psp |= low;
+                else if (rab) pnl |= low;
+                first_kept = false;
+            }
+        }
+        if (keep) g |= m;
+        if (last_part) t++;
+    });
+    flush(cur_w);
     return true;
 }
 
@@ -799,7 +922,7 @@ struct PlanShared {
     u64 tokc[TILE_BLOCKS];
     u64 marks[TILE_BLOCKS];
     uint16_t list[G3_LCAP];
-    G3Tok tok[NT / 64][G3_MAXT];
+    u32 tok[NT / 64][G3_MAXT];
     u32 scan32[NT / 64];
     u32 nlist;
     u64 g3base;
@@ -872,11 +995,10 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
             __syncthreads();
             const u32 nl = tot < G3_LCAP ? tot : G3_LCAP;
             const u32 tile_valid = (u32)(N - tS < (u64)TILE ? N - tS : (u64)TILE);
-            for (u32 i = wave; i < nl; i += NT / 64) {
+            for (u32 i = tid; i < nl; i += NT) {   // one line per lane
                 const u32 ent = sh.list[i], s0 = ent & 0x3FFFu;
-                if (g3_wave_solve(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
-                                  tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, cfg.max_digit_ratio, sh.tok[wave],
-                                  (u64*)nullptr) && lane == 0)
+                if (g3_lane_solve(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
+                                  tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, cfg.max_digit_ratio))
                     atomicAnd(reinterpret_cast<unsigned long long*>(&sh.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
             }
             __syncthreads();
@@ -1045,7 +1167,7 @@ __global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
                                                      u32* tile_toks, u64* __restrict__ totals) {
     __shared__ u64 masks[NT / 64][8][G3_VIEW + 1];
-    __shared__ G3Tok tok[NT / 64][G3_MAXT];
+    __shared__ u32 tok[NT / 64][G3_MAXT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u64 n = *mark_total;
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[4] = n; totals[5] = n > cap ? 1 : 0; }
@@ -1081,8 +1203,7 @@ __global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes
         G3Masks gm = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]};
         const u64 view0 = w0 * 64;
         const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
-        u64 km = 0;
-        const bool ok = g3_wave_solve(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio, tok[wave], &km);
+        const bool ok = g3_wave_solve(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio, tok[wave]);
         __threadfence_block();
         const u64 mb = ~(1ull << (p & 63));
         if (lane == 0) {   // the marker's flag bits
