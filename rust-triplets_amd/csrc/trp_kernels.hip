@@ -1319,7 +1319,7 @@ struct EmitScan {
     u32 nb, ntk, nte;   // emitted bytes, token starts, token ends
     int lts;            // tile-relative byte position of the last token start so far, -1 none
 };
-constexpr u32 TOK_CAP = 4096;   // tokens per tile staged in LDS (16 KiB); the rest is stored directly
+constexpr u32 TOK_CAP = 2304;   // tokens per tile staged in LDS (9 KiB); the rest is stored directly
 struct EmitOp {
     __device__ EmitScan operator()(const EmitScan& a, const EmitScan& b) const {
         EmitScan r;
@@ -1333,12 +1333,19 @@ struct EmitOp {
 
 struct Pair32 { u32 lo, hi; };   // two consecutive dwords at a 4-byte aligned address
 
+// Once the run copies are done the input image is dead; its space then holds the staged token table and
+// the per-block words the record-offset loop needs.
+struct EmitLate {
+    u32 tokstage[TOK_CAP];
+    u64 cw[TILE_BLOCKS], pfx[TILE_BLOCKS], ts[TILE_BLOCKS];
+    u32 eb[TILE_BLOCKS], tb[TILE_BLOCKS];
+};
+static_assert(sizeof(EmitLate) <= sizeof(TileShared), "late emit data must fit in the input image");
+
 struct EmitShared {
     TileShared tile;
     alignas(16) u8 out[TILE + 64];   // output image of the tile (linear)
     u64 tokc[TILE_BLOCKS];
-    u64 cw[TILE_BLOCKS], pfx[TILE_BLOCKS], ts[TILE_BLOCKS];
-    u32 eb[TILE_BLOCKS], tb[TILE_BLOCKS];
     EmitScan scan[NT / 64];
     EmitScan total;
     u64 cin_start;      // corpus position where the token that runs into this tile starts
@@ -1471,11 +1478,6 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     const u32 out0 = PASSTHROUGH ? (u32)tS : seed.nb;   // output position of the tile's first byte
     const u32 tok0 = seed.ntk;                           // index of the first token that starts in the tile
     const u32 shift = PASSTHROUGH ? 0 : (out0 & 15u);
-    sh.cw[tid] = pl.C;
-    sh.pfx[tid] = PFX;
-    sh.ts[tid] = TS;
-    sh.eb[tid] = ex.nb;
-    sh.tb[tid] = ex.ntk;
     if (tid == 0) {
         sh.total = tot;
         // does a token run into this tile from the left?  Find where it starts.
@@ -1545,7 +1547,13 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     if (stop_after == 3) { __syncthreads(); continue; }
     // tokens: one (start, len) record per token end.  Tokens that start and end inside the tile are
     // staged in LDS (the input image is no longer needed) and stored with coalesced writes below.
-    u32* tokstage = reinterpret_cast<u32*>(sh.tile.bytes);
+    EmitLate& late = *reinterpret_cast<EmitLate*>(sh.tile.bytes);
+    u32* tokstage = late.tokstage;
+    late.cw[tid] = pl.C;
+    late.pfx[tid] = PFX;
+    late.ts[tid] = TS;
+    late.eb[tid] = ex.nb;
+    late.tb[tid] = ex.ntk;
     {
         const bool plain = PASSTHROUGH || (pl.C == V && PFX == 0);   // output position = ex.nb + bit index
         auto outpos = [&](int j) -> u32 {   // output position of the (copied) byte at bit j
@@ -1598,8 +1606,8 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
             if (q >= N) continue;
             u32 l = (u32)((q - tS) >> 6), j = (u32)((q - tS) & 63);
             u64 lowm = below((int)j);
-            den_off[r] = PASSTHROUGH ? q : (u64)(sh.eb[l] + popc(sh.cw[l] & lowm) + popc(sh.pfx[l] & lowm));
-            tok_off[r] = (u64)(sh.tb[l] + popc(sh.ts[l] & lowm));
+            den_off[r] = PASSTHROUGH ? q : (u64)(late.eb[l] + popc(late.cw[l] & lowm) + popc(late.pfx[l] & lowm));
+            tok_off[r] = (u64)(late.tb[l] + popc(late.ts[l] & lowm));
         }
     }
     if (stop_after == 5) { __syncthreads(); continue; }
