@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--bytes", type=int, default=1_000_000_000, help="bytes per GPU")
     ap.add_argument("--config", default="B", choices=["B", "C", "D"])
     ap.add_argument("--no-denoise", action="store_true")
+    ap.add_argument("--normalize", action="store_true",
+                    help="time normalize_inline_whitespace (the step before the path) instead of the path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="also time trp_preprocess_batch on host buffers (PCIe both ways included)")
@@ -96,6 +98,8 @@ def main():
     ctx = T.Context(local_rank)
 
     def step():
+        if args.normalize:
+            return ctx.normalize_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N)
         return ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
 
     for _ in range(args.warmup):
@@ -160,7 +164,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R,
-                   "denoiser": "enabled" if den.enabled else "disabled",
+                   "denoiser": "normalize_inline_whitespace" if args.normalize else ("enabled" if den.enabled else "disabled"),
                    "chunking": "max_window_tokens=1024 overlap=[64] summary_fallback_tokens=512",
                    "sharding": "record ranges, one shard per GPU, no collective"},
         "outputs": {"denoised_bytes": stats["D"], "tokens": stats["T"], "chunks": stats["C"]},
@@ -188,7 +192,7 @@ def main():
                             "note": "pinned input, H2D + kernels + D2H of all result arrays, best of 3"}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 only ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.normalize:
         import oracle_lib as O
         cfg = O.make_config(den.enabled, 0.35, True, 1024, (64,), 512)
         cut = int(np.searchsorted(offs, min(N, 256_000_000), side="right")) - 1

@@ -138,6 +138,21 @@ int trp_copy_to_host(trp_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int trp_materialize_chunk_text_device(trp_ctx* ctx, uint8_t** d_text, uint64_t** d_text_offsets,
                                       uint64_t* n_text_bytes);
 
+/* normalize_inline_whitespace (src/utils.rs:18-33) for every record of a batch: each run of White_Space
+ * characters becomes one ' ' and the result is trimmed.  The File and CSV sources apply it to every text
+ * they ingest (src/source/backends/file_source.rs:260, csv_source.rs:280-310), i.e. it is the step just
+ * before the preprocessing path.  Same calling conventions and result layout as trp_preprocess_batch /
+ * trp_preprocess_batch_device: `denoised` holds the normalised text, the token table its tokens, the
+ * chunk descriptors are those of the reference's default chunking, dropped[] is all zero (the function
+ * never returns None; an all-whitespace record becomes the empty string). */
+int trp_normalize_batch(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                        trp_result* out);
+int trp_normalize_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                               uint64_t n_records, uint64_t n_bytes, trp_result* out);
+/* One text (a batch of one): malloc'd copy in *out (free with trp_free). */
+int trp_normalize_inline_whitespace(trp_ctx* ctx, const uint8_t* text, size_t len, uint8_t** out,
+                                    size_t* out_len);
+
 /* Single-record conveniences mirroring the reference's public functions (each runs a batch of one).
  * trp_denoise: denoise_text (denoiser_preprocessor.rs:221): returns 1 for Some(text) with a malloc'd
  *   copy in *out (free with trp_free), 0 for None, negative on error.

@@ -492,11 +492,12 @@ struct LaneCtx {
     u64 p;          // byte offset of the block in the corpus
     int nvalid;
     bool next_rs;   // the byte after the block starts a record or does not exist
+    bool prev_tok;  // normalize mode: the byte before the block is a token byte of the same record
 };
 
 // rs_here / rs_next: record-start words of this block and of the next one (rsmap has one spare word).
 __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, u64 N, u64 tS, bool want_lines,
-                                     u64 rs_here, u64 rs_next) {
+                                     u64 rs_here, u64 rs_next, bool normalize = false) {
     LaneCtx L;
     const int tid = threadIdx.x;
     const PadBlk blk = lane_block(sh, tid);
@@ -508,7 +509,12 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
     bool nrs = (rs_next & 1ull) != 0;
     bool has_next = L.p + BLOCK < N;
     L.next_rs = !has_next || nrs;
-    if (want_lines) {
+    L.prev_tok = false;
+    if (normalize) {
+        L.prev_tok = L.p > 0 && L.nvalid > 0 && !(RS & 1ull) && !byte_is_ws(blk, -1);
+        L.c = normalize_cls(L.c, V);
+        L.d = derive(L.c, V, RS, false, false);
+    } else if (want_lines) {
         bool next_nl = has_next && blk[BLOCK] == '\n' && !nrs;
         bool pt = prev_is_term(L.p > 0, blk[-1], L.nvalid > 0, blk[0], (RS & 1ull) != 0);
         L.d = derive(L.c, V, RS, next_nl, pt);
@@ -542,7 +548,7 @@ __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, 
 // ---------------------------------------------------------------------------------------------------
 constexpr int SUM_TPW = 1;   // consecutive tiles per workgroup (the next one is loaded during the current one)
 __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
-                                                 u64 nB, u64 nT, J* __restrict__ SA) {
+                                                 u64 nB, u64 nT, u32 normalize, J* __restrict__ SA) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ J wsum[NT / 64];
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, co
         tile_store(regs, sh.bytes);
         const u64 rs_h = rs_here, rs_n = rs_next;
         __syncthreads();
-        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs_h, rs_n);
+        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs_h, rs_n, normalize != 0);
         // the next tile's loads are issued after the register-hungry classification
         if (i + 1 < SUM_TPW && t + 1 < nT) {
             tile_load(bytes, N, tS + TILE, regs);
@@ -948,7 +954,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     if (tid == 64) sh.seed_s = seedS[t];
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
-    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, rs_here, rs_next);
+    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, rs_here, rs_next, cfg.normalize != 0);
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
     const WaveLines W = wave_lines(lane_J(L.c, L.d));
     {
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
-    Plan pl = plan_block(L.c, L.d, k, cfg);
+    Plan pl = cfg.normalize ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok) : plan_block(L.c, L.d, k, cfg);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -1650,7 +1656,7 @@ __global__ void k_chunk_count(const u64* __restrict__ den_off, const u64* __rest
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     counts[r] = chunk_count(tok_off[r + 1] - tok_off[r], cfg);
-    dropped[r] = cfg.denoise_enabled && den_off[r + 1] == den_off[r];
+    dropped[r] = cfg.denoise_enabled && !cfg.normalize && den_off[r + 1] == den_off[r];
 }
 
 // grid-stride over all chunks; the record of a chunk is found by binary search in chunk_offsets
@@ -1917,16 +1923,14 @@ int trp_get_profile(trp_ctx* c, trp_kernel_time* out, int cap) {
     return n;
 }
 
-int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R,
-                                uint64_t N, const trp_config* cfg, trp_result* out) {
+static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
+                      const DevCfg& dc, trp_result* out) {
     if (!c || !out) return fail(TRP_E_ARG, "ctx/out is null");
     if (!d_offsets) return fail(TRP_E_ARG, "offsets is null");
     if (N && !d_bytes) return fail(TRP_E_ARG, "bytes is null");
     if (((uintptr_t)d_bytes & 15u) != 0) return fail(TRP_E_ARG, "bytes must be 16-byte aligned");
     if (N > TRP_MAX_BATCH_BYTES || R >= 0xFFFFFFFEull) return fail(TRP_E_TOO_LARGE, "batch too large: split it by record range");
-    DevCfg dc;
-    int rc = make_devcfg(cfg, &dc);
-    if (rc) return rc;
+    int rc;
     HIPCHK(hipSetDevice(c->device));
     c->have_last = false;
     const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE;
@@ -1987,7 +1991,7 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
         if (!pass) {
             { Prof pr(c, "k_summary");
               hipLaunchKernelGGL(k_summary, dim3((unsigned)((nT + SUM_TPW - 1) / SUM_TPW)), dim3(NT), 0, st, d_bytes, rsmap, N, nB,
-                                 nT, SA); }
+                                 nT, dc.normalize, SA); }
             { Prof pr(c, "k_tile_carry");
               hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)((nT + NT / 64 - 1) / (NT / 64))), dim3(NT), 0, st, SA, nT,
                                  c->seedJ.as<J>(), c->seedS.as<S>()); }
@@ -2036,7 +2040,7 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
         // more digit-heavy lines than the work list holds: grow it to the exact size and run the batch again
         if (c->h_totals[4] <= g3_cap) return fail(TRP_E_HIP, "inconsistent gate-3 list size");
         if ((rc = c->g3list.ensure(c->h_totals[4] * sizeof(u64)))) return rc;
-        return trp_preprocess_batch_device(c, d_bytes, d_offsets, R, N, cfg, out);
+        return run_device(c, d_bytes, d_offsets, R, N, dc, out);
     }
     if (c->h_totals[3]) {
         // the optimistic descriptor buffer was too small: grow to the exact size and emit again
@@ -2107,6 +2111,32 @@ int trp_materialize_chunk_text_device(trp_ctx* c, uint8_t** d_text, uint64_t** d
     *d_text_offsets = c->text_off.as<u64>();
     *n_text_bytes = nbytes;
     return TRP_OK;
+}
+
+static DevCfg normalize_devcfg() {
+    DevCfg dc;
+    memset(&dc, 0, sizeof(dc));
+    dc.denoise_enabled = 1;        // runs the planning kernels ...
+    dc.normalize = 1;              // ... with the whitespace-normalising plan instead of the denoiser gates
+    dc.max_digit_ratio = 0.35f;
+    dc.max_window_tokens = 1024;   // reference defaults for the chunk descriptors that come with the result
+    dc.n_overlaps = 1;
+    dc.overlaps[0] = 64;
+    dc.summary_fallback_tokens = 512;
+    return dc;
+}
+
+int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R,
+                                uint64_t N, const trp_config* cfg, trp_result* out) {
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    return run_device(c, d_bytes, d_offsets, R, N, dc, out);
+}
+
+int trp_normalize_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R,
+                               uint64_t N, trp_result* out) {
+    return run_device(c, d_bytes, d_offsets, R, N, normalize_devcfg(), out);
 }
 
 int trp_copy_to_host(trp_ctx* c, void* dst, const void* d_src, size_t bytes) {
@@ -2202,8 +2232,8 @@ void trp_free(void* p) { host_pool().release(p); }
 
 void trp_trim_host_pool(void) { host_pool().trim(); }
 
-int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const trp_config* cfg,
-                         trp_result* out) {
+static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
+                    trp_result* out) {
     if (!c || !out || !offsets) return fail(TRP_E_ARG, "null argument");
     if (offsets[0] != 0) return fail(TRP_E_ARG, "offsets[0] must be 0");
     const u64 N = offsets[R];
@@ -2215,7 +2245,7 @@ int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
     if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     trp_result d;
-    rc = trp_preprocess_batch_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, cfg, &d);
+    rc = run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, &d);
     if (rc) return rc;
     memset(out, 0, sizeof(*out));
     out->n_records = R; out->n_denoised = d.n_denoised; out->n_tokens = d.n_tokens; out->n_chunks = d.n_chunks;
@@ -2237,6 +2267,31 @@ int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
     if ((rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return rc;
     if ((rc = grab((void**)&out->chunk_offsets, d.chunk_offsets, (R + 1) * sizeof(u64)))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    return TRP_OK;
+}
+
+int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const trp_config* cfg,
+                         trp_result* out) {
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    return run_host(c, bytes, offsets, R, dc, out);
+}
+
+int trp_normalize_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, trp_result* out) {
+    return run_host(c, bytes, offsets, R, normalize_devcfg(), out);
+}
+
+int trp_normalize_inline_whitespace(trp_ctx* c, const uint8_t* text, size_t len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len) return fail(TRP_E_ARG, "null argument");
+    uint64_t offs[2] = {0, (uint64_t)len};
+    trp_result r;
+    int rc = trp_normalize_batch(c, text, offs, 1, &r);
+    if (rc) return rc;
+    *out_len = (size_t)r.n_denoised;
+    *out = r.denoised;
+    r.denoised = nullptr;
+    trp_result_free(&r);
     return TRP_OK;
 }
 

@@ -498,6 +498,7 @@ struct DevCfg {
     u32 n_overlaps;
     u32 summary_fallback_tokens;
     u32 overlaps[MAX_OVERLAPS];
+    u32 normalize;   // 1: normalize_inline_whitespace instead of the denoiser (see plan_normalize)
 };
 
 // digits as f32 / (digits + alpha) as f32 > max   (denoiser_preprocessor.rs:37-45, :115-121)
@@ -541,6 +542,36 @@ struct LaneCarry {
     LineSum co;     // the rest of the block's last line after the end of this block
     bool next_rs;   // the byte after this block starts a record (or does not exist)
 };
+
+// ---- normalize_inline_whitespace (src/utils.rs:18-33) on the same machinery ------------------------
+// The reference collapses every run of White_Space characters into one ' ' and trims the result, i.e.
+// the output is the record's whitespace-separated tokens joined by single spaces.  As an emit plan:
+// copy the token bytes, and put one ' ' in front of every token start except the first of its record.
+// "The record has a token before this block" is the record-level flag the denoiser machinery already
+// carries for alphabetic characters, so this mode classifies every non-whitespace byte as alphabetic
+// and knows no line terminators.
+TRP_HD Cls normalize_cls(const Cls& c, u64 V) {
+    Cls n = {c.ws, 0, 0, 0, 0, V & ~c.ws, 0};
+    return n;
+}
+// prev_tok: the byte before the block exists, belongs to the same record and is not whitespace.
+TRP_HD Plan plan_normalize(const Cls& c, const Derived& d, bool ar_in, bool prev_tok) {
+    const u64 T = d.V & ~c.ws;
+    const u64 TS = T & (~((T << 1) | (prev_tok ? 1ull : 0ull)) | d.RS);
+    u64 first = 0;   // the first token start of every record that starts in, or reaches, this block
+    if (!ar_in) {
+        const u64 x = TS & (d.RS ? below(ctz(d.RS)) : ~0ull);
+        first |= x & (0ull - x);
+    }
+    for (u64 rs = d.RS; rs;) {
+        const int r = ctz(rs);
+        rs &= rs - 1;
+        const u64 x = TS & ~below(r) & (rs ? below(ctz(rs)) : ~0ull);
+        first |= x & (0ull - x);
+    }
+    Plan p = {T, T, TS & ~first, 0};
+    return p;
+}
 
 TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
     LaneCarry k;

@@ -44,6 +44,7 @@ struct sim_result {
 int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const sim_config* scfg,
                   sim_result* out, int tile_blocks);
 void trp_sim_free(sim_result* r);
+int trp_sim_normalize(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, sim_result* out, int tile_blocks);
 int trp_sim_check_monoids(unsigned seed, int iters);
 }
 
@@ -81,9 +82,30 @@ struct PlanBits {
 };
 }  // namespace
 
+static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& cfg, sim_result* out,
+                   int tile_blocks);
+
 int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const sim_config* scfg,
                   sim_result* out, int tile_blocks) {
-    DevCfg cfg = to_dev(scfg);
+    return sim_run(bytes, offsets, R, to_dev(scfg), out, tile_blocks);
+}
+
+// normalize_inline_whitespace of every record, with the reference's default chunking on the result
+int trp_sim_normalize(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, sim_result* out, int tile_blocks) {
+    DevCfg d;
+    memset(&d, 0, sizeof(d));
+    d.denoise_enabled = 1;
+    d.normalize = 1;
+    d.max_digit_ratio = 0.35f;
+    d.max_window_tokens = 1024;
+    d.n_overlaps = 1;
+    d.overlaps[0] = 64;
+    d.summary_fallback_tokens = 512;
+    return sim_run(bytes, offsets, R, d, out, tile_blocks);
+}
+
+static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& cfg, sim_result* out,
+                   int tile_blocks) {
     UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
     const u64 N = offsets[R];
     const u64 nB = (N + 63) / 64;
@@ -119,6 +141,10 @@ int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, con
             u64 p = b * 64;
             bool next_nl = (p + 64 < N) && base[p + 64] == '\n' && !rs_at(p + 64);
             bool pt = prev_is_term(p > 0, p > 0 ? base[p - 1] : 0, true, base[p], rs_at(p));
+            if (cfg.normalize) {
+                cls[b] = normalize_cls(cls[b], Vm[b]);
+                next_nl = pt = false;
+            }
             der[b] = derive(cls[b], Vm[b], RSw[b], next_nl, pt);
             jl[b] = lane_J(cls[b], der[b]);
         }
@@ -154,7 +180,13 @@ int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, con
             for (u64 b = b0; b < b1; b++) {
                 bool next_rs = ((b + 1) * 64 >= N) || rs_at((b + 1) * 64);
                 LaneCarry k = carry_from(pre, suf[b - b0], next_rs);
-                plan[b] = plan_block(cls[b], der[b], k, cfg);
+                if (cfg.normalize) {
+                    u64 p = b * 64;
+                    bool prev_tok = p > 0 && !rs_at(p) && !byte_is_ws(PlainBlk{base + p}, -1);
+                    plan[b] = plan_normalize(cls[b], der[b], k.ar_in, prev_tok);
+                } else {
+                    plan[b] = plan_block(cls[b], der[b], k, cfg);
+                }
                 pre = j_combine(pre, jl[b]);
             }
         }
@@ -260,7 +292,7 @@ int trp_sim_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, con
     for (u64 i = 0; i < R; i++) {
         out->chunk_offsets[i] = C;
         C += chunk_count(toff[i + 1] - toff[i], cfg);
-        out->dropped[i] = cfg.denoise_enabled && doff[i + 1] == doff[i];
+        out->dropped[i] = cfg.denoise_enabled && !cfg.normalize && doff[i + 1] == doff[i];
     }
     out->chunk_offsets[R] = C;
     out->n_chunks = C;

@@ -46,6 +46,19 @@ int main() {
         sd.register_denoiser(dc);
         auto none = chunker.materialize(sd, "r2", 1, "1234 5678\n99");
         EXPECT(none.empty());
+        EXPECT(normalize_inline_whitespace(ctx, "Alpha\r\n\r\n  Beta\tGamma") == "Alpha Beta Gamma");
+        EXPECT(normalize_inline_whitespace(ctx, " \n ") == "");
+
+        ChunkCache cache(ctx);
+        cache.prefill(st, {{"r1", 0, "one two three four five six seven"}, {"r1", 1, "a b"}, {"r9", 0, ""}});
+        EXPECT(cache.size() == 3 && cache.token_count("r1", 0).value() == 7 && cache.token_count("r9", 0).value() == 0);
+        auto c0 = cache.materialize(st, "r1", 0, "ignored: served from the table");
+        EXPECT(c0.size() == 3 && c0[1].text == "four five six seven" && c0[0].record_id == "r1");
+        auto c1 = cache.materialize(st, "r1", 1, "a b");
+        EXPECT(c1.size() == 1 && c1[0].text == "a b" && c1[0].view.span == 2 && c1[0].section_idx == 1);
+        EXPECT(cache.materialize(st, "r9", 0, "").empty());
+        auto miss = cache.materialize(st, "r2", 4, "x y z");   // not prefilled: a batch of one
+        EXPECT(miss.size() == 1 && miss[0].tokens_estimate == 3 && cache.size() == 4);
         std::puts("host_check: ok");
         return 0;
     } catch (const Error& e) {

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -231,6 +232,16 @@ private:
     Context& ctx_;
 };
 
+// normalize_inline_whitespace (src/utils.rs:18-33): whitespace runs -> one space, trimmed.
+inline std::string normalize_inline_whitespace(Context& ctx, std::string_view text) {
+    uint8_t* out = nullptr;
+    size_t len = 0;
+    check(trp_normalize_inline_whitespace(ctx.raw(), reinterpret_cast<const uint8_t*>(text.data()), text.size(), &out, &len));
+    std::string s(reinterpret_cast<char*>(out), len);
+    trp_free(out);
+    return s;
+}
+
 class SlidingWindowChunker {
 public:
     explicit SlidingWindowChunker(Context& ctx) : ctx_(ctx) {}
@@ -243,6 +254,58 @@ public:
 
 private:
     Context& ctx_;
+};
+
+// Chunk table filled by one GPU batch and served per (record id, section index): what a sampler needs to
+// call a GPU-backed chunker once per chunk selection (the reference calls ChunkingAlgorithm::materialize
+// per selection, src/sampler/mod.rs:2510-2537, and re-tokenises every section when it refreshes its
+// record cache, :1803-1836 - the place to call prefill).  token_count answers what
+// record_has_long_anchor_or_context_section (:1765-1773) asks without tokenising again.
+class ChunkCache {
+public:
+    struct SectionRef {
+        std::string record_id;
+        size_t section_idx;
+        std::string_view text;
+    };
+    explicit ChunkCache(Context& ctx) : ctx_(ctx) {}
+
+    void prefill(const ChunkingStrategy& st, const std::vector<SectionRef>& sections) {
+        std::vector<std::string_view> texts;
+        texts.reserve(sections.size());
+        for (const auto& s : sections) texts.push_back(s.text);
+        BatchPreprocessor bp(ctx_);
+        BatchResult r = bp.run(texts, st);
+        for (size_t i = 0; i < sections.size(); i++) {
+            Entry e;
+            e.chunks = r.chunks(i, sections[i].record_id, sections[i].section_idx);
+            e.tokens = r.token_count(i);
+            table_[{sections[i].record_id, sections[i].section_idx}] = std::move(e);
+        }
+    }
+    // The chunks of one section; a section that was not prefilled is computed as a batch of one.
+    std::vector<RecordChunk> materialize(const ChunkingStrategy& st, const std::string& record_id, size_t section_idx,
+                                         std::string_view section_text) {
+        auto it = table_.find({record_id, section_idx});
+        if (it != table_.end()) return it->second.chunks;
+        prefill(st, {SectionRef{record_id, section_idx, section_text}});
+        return table_[{record_id, section_idx}].chunks;
+    }
+    std::optional<size_t> token_count(const std::string& record_id, size_t section_idx) const {
+        auto it = table_.find({record_id, section_idx});
+        if (it == table_.end()) return std::nullopt;
+        return it->second.tokens;
+    }
+    size_t size() const { return table_.size(); }
+    void clear() { table_.clear(); }
+
+private:
+    struct Entry {
+        std::vector<RecordChunk> chunks;
+        size_t tokens = 0;
+    };
+    Context& ctx_;
+    std::map<std::pair<std::string, size_t>, Entry> table_;
 };
 
 }  // namespace triplets_amd

@@ -71,5 +71,19 @@ extern "C" {
         out_len: *mut usize,
     ) -> c_int;
     pub fn trp_token_count(ctx: *mut trp_ctx, text: *const u8, len: usize, n: *mut usize) -> c_int;
+    pub fn trp_normalize_batch(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        out: *mut trp_result,
+    ) -> c_int;
+    pub fn trp_normalize_inline_whitespace(
+        ctx: *mut trp_ctx,
+        text: *const u8,
+        len: usize,
+        out: *mut *mut u8,
+        out_len: *mut usize,
+    ) -> c_int;
     pub fn trp_free(p: *mut c_void);
 }

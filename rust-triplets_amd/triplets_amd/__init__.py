@@ -59,7 +59,8 @@ CHUNK_DTYPE = np.dtype([(n, "<u4") for n in
 EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_preprocess_batch",
            "trp_result_free", "trp_preprocess_batch_device", "trp_copy_to_host",
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
-           "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool"]
+           "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
+           "trp_normalize_batch_device", "trp_normalize_inline_whitespace"]
 
 _lib = None
 
@@ -103,6 +104,11 @@ def load_library():
     L.trp_free.argtypes = [C.c_void_p]
     L.trp_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.trp_get_profile.argtypes = [C.c_void_p, C.POINTER(_KernelTime), C.c_int]
+    L.trp_normalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Result)]
+    L.trp_normalize_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                             C.POINTER(_Result)]
+    L.trp_normalize_inline_whitespace.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -308,17 +314,7 @@ class Context:
     def stream(self) -> int:
         return self._L.trp_stream(self._h) or 0
 
-    def preprocess_batch(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
-                         strategy: ChunkingStrategy) -> BatchResult:
-        """Packed batch in host memory -> host result (copies in and out)."""
-        data = np.ascontiguousarray(data, dtype=np.uint8)
-        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        R = len(offsets) - 1
-        cfg = _make_cfg(denoiser, strategy)
-        res = _Result()
-        _check(self._L.trp_preprocess_batch(self._h, data.ctypes.data if data.size else None,
-                                            offsets.ctypes.data, R, C.byref(cfg), C.byref(res)))
-
+    def _host_result(self, res, R) -> "BatchResult":
         def arr(ptr, n, dt):
             dt = np.dtype(dt)
             if not n:
@@ -338,6 +334,33 @@ class Context:
             n_chunks=int(res.n_chunks))
         self._L.trp_result_free(C.byref(res))
         return out
+
+    def preprocess_batch(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
+                         strategy: ChunkingStrategy) -> BatchResult:
+        """Packed batch in host memory -> host result (copies in and out)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        R = len(offsets) - 1
+        cfg = _make_cfg(denoiser, strategy)
+        res = _Result()
+        _check(self._L.trp_preprocess_batch(self._h, data.ctypes.data if data.size else None,
+                                            offsets.ctypes.data, R, C.byref(cfg), C.byref(res)))
+        return self._host_result(res, R)
+
+    def normalize_batch(self, data: np.ndarray, offsets: np.ndarray) -> BatchResult:
+        """normalize_inline_whitespace (src/utils.rs:18-33) of every record of a packed host batch."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        R = len(offsets) - 1
+        res = _Result()
+        _check(self._L.trp_normalize_batch(self._h, data.ctypes.data if data.size else None,
+                                           offsets.ctypes.data, R, C.byref(res)))
+        return self._host_result(res, R)
+
+    def normalize_batch_device(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int) -> "DeviceResult":
+        res = _Result()
+        _check(self._L.trp_normalize_batch_device(self._h, d_bytes, d_offsets, n_records, n_bytes, C.byref(res)))
+        return DeviceResult(self, res)
 
     def preprocess_batch_device(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int,
                                 denoiser: DenoiserConfig, strategy: ChunkingStrategy) -> DeviceResult:
@@ -403,6 +426,19 @@ def denoise_text(text: str, config: DenoiserConfig, ctx: Context = None) -> Opti
     s = C.string_at(out, n.value) if n.value else b""
     ctx._L.trp_free(out)
     return s.decode("utf-8")
+
+
+def normalize_inline_whitespace(text: str, ctx: Context = None) -> str:
+    """src/utils.rs:18-33 for one text (a batch of one)."""
+    ctx = ctx or default_context()
+    raw = text.encode("utf-8")
+    out = C.c_void_p()
+    n = C.c_size_t()
+    _check(ctx._L.trp_normalize_inline_whitespace(ctx._h, raw, len(raw), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value).decode("utf-8")
+    finally:
+        ctx._L.trp_free(out)
 
 
 class DenoiserPreprocessor:
