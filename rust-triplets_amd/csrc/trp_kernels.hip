@@ -146,88 +146,7 @@ __device__ inline T block_scan_excl_bwd(T v, Op op, T identity, T seed, T* smem)
     return res;
 }
 
-// ---- wave-uniform summaries from ballots -------------------------------------------------------------
-// The forward summary J of the 64 blocks of a wavefront, computed without moving data between lanes:
-// counts are summed as popcounts of the ballots of their bit planes (a block holds at most 64 of
-// anything, so seven planes), flags come from ballots directly.  The result is the same value as the
-// ordered fold of j_combine over the lanes and is uniform across the wave.
-struct LineSumBallots {
-    u64 d[7], a[7], p[7];
-    u64 nz, first_pipe, last_pipe, seen;
-};
-__device__ inline LineSumBallots ballots_of(const LineSum& x) {
-    LineSumBallots B;
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        B.d[k] = __ballot((x.d >> k) & 1u);
-        B.a[k] = __ballot((x.a >> k) & 1u);
-        B.p[k] = __ballot((x.p >> k) & 1u);
-    }
-    B.nz = __ballot(ls_first(x) != 0);
-    B.first_pipe = __ballot(ls_first(x) == 1u);
-    B.last_pipe = __ballot(ls_last(x) == 1u);
-    B.seen = __ballot(ls_seen_text(x));
-    return B;
-}
-// Sum (in lane order) of the LineSums of the lanes in mask m.
-__device__ inline LineSum ballots_sum(const LineSumBallots& B, u64 m) {
-    LineSum s = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        s.d += (u32)popc(B.d[k] & m) << k;
-        s.a += (u32)popc(B.a[k] & m) << k;
-        s.p += (u32)popc(B.p[k] & m) << k;
-    }
-    const u64 nz = B.nz & m;
-    if (nz) {
-        const u32 first = ((B.first_pipe >> ctz(nz)) & 1ull) ? 1u : 2u;
-        const u32 last = ((B.last_pipe >> top(nz)) & 1ull) ? 1u : 2u;
-        s.f = first | (last << 2) | ((B.seen & m) ? 16u : 0u);
-    }
-    return s;
-}
 __device__ inline u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
-__device__ inline LineSum readlane_ls(const LineSum& x, int lane) {
-    LineSum r = {readlane_u32(x.d, lane), readlane_u32(x.a, lane), readlane_u32(x.p, lane), readlane_u32(x.f, lane)};
-    return r;
-}
-
-__device__ inline J wave_J(const J& j) {
-    const u64 lsm = __ballot((j.g & G_LS) != 0), rsm = __ballot((j.g & G_RS) != 0);
-    const u64 gah = __ballot((j.g & G_AH) != 0), gat = __ballot((j.g & G_AT) != 0);
-    const LineSumBallots B = ballots_of(j.head);
-    J r;
-    u32 g = 0;
-    if (!lsm) {
-        r.head = ballots_sum(B, ~0ull);
-        r.tail = ls_empty();
-    } else {
-        const int f = ctz(lsm), l = top(lsm);
-        r.head = ballots_sum(B, below(f + 1));
-        r.tail = ls_add(readlane_ls(j.tail, l), ballots_sum(B, ~below(l + 1)));
-        g |= G_LS;
-        const bool c0l = (__ballot((j.g & G_C0) != 0) >> l) & 1ull, c1l = (__ballot((j.g & G_C1) != 0) >> l) & 1ull;
-        const u64 rs_before = rsm & below(l);
-        bool known;
-        if (rs_before) {
-            const int r0 = top(rs_before);
-            known = ((gat >> r0) & 1ull) || (gah & below(l) & ~below(r0 + 1)) != 0;
-        } else {
-            known = (gah & below(l)) != 0;
-            if (c1l) g |= G_C1;
-        }
-        if (c0l || (c1l && known)) g |= G_C0;
-    }
-    if (!rsm) {
-        if (gah) g |= G_AH | G_AT;
-    } else {
-        g |= G_RS;
-        if (gah & below(ctz(rsm) + 1)) g |= G_AH;
-        if (gat & ~below(top(rsm))) g |= G_AT;
-    }
-    r.g = g;
-    return r;
-}
 
 // ---- line carries of a tile from wave prefix sums and ballots ----------------------------------------
 // What a lane has to know about the blocks around it (LaneCarry) is a segmented sum over the lanes back
@@ -1145,9 +1064,9 @@ __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* 
     }
     u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
     bool first = true;
-    g3_walk(src, p, e, table, ut, K, ~0ull - 1, (u64*)nullptr, (u64*)nullptr,
-            [&](const TokInfo& tk, bool keep) {
-                if (!keep) return;
+    g3_walk(src, p, e, table, ut,
+            [&](const TokInfo& tk, u64 dist) {
+                if (dist > K) return;
                 u64 w0 = tk.ts >> 6, w1 = (tk.te - 1) >> 6;
                 for (u64 w = w0; w <= w1; w++) {
                     u64 lo_b = w == w0 ? (tk.ts & 63) : 0;
@@ -1584,12 +1503,49 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
                 te &= te - 1;
             }
         }
-        while (te) {   // from here on starts and ends alternate
-            int s0 = ctz(ts), x = ctz(te);
-            ts &= ts - 1;
-            te &= te - 1;
-            put(idx, outpos(s0), (u32)(x - s0 + 1), true);
-            idx++;
+        // From here on starts and ends alternate.  The 64 bits are walked as two 32-bit halves, with the
+        // token that straddles the halves in between.  Output position of the byte at bit j: the bit
+        // index minus the bytes dropped below j plus the separators inserted up to j.
+        const u32 slot0 = idx - tok0;
+        if (slot0 + (u32)popc(ts) <= TOK_CAP) {
+            u32* slot = tokstage + slot0;
+            const u32 base = PASSTHROUGH ? (u32)(p - tS) : ex.nb - out0;
+            const u64 drops = PASSTHROUGH ? 0ull : ~pl.C;
+            const u64 pfx = PASSTHROUGH ? 0ull : PFX;
+            const u32 dl = (u32)drops, dh = (u32)(drops >> 32), ql = (u32)pfx, qh = (u32)(pfx >> 32);
+            auto pos_lo = [&](u32 j) -> u32 {
+                return base + j - (u32)__builtin_popcount(dl & ((1u << j) - 1u)) + (u32)__builtin_popcount(ql & ((2u << j) - 1u));
+            };
+            const u32 base_hi = base + 32u - (u32)__builtin_popcount(dl) + (u32)__builtin_popcount(ql);
+            auto pos_hi = [&](u32 j) -> u32 {
+                return base_hi + j - (u32)__builtin_popcount(dh & ((1u << j) - 1u)) + (u32)__builtin_popcount(qh & ((2u << j) - 1u));
+            };
+            u32 tsl = (u32)ts, tsh = (u32)(ts >> 32), tel = (u32)te, teh = (u32)(te >> 32);
+            while (tel) {
+                const u32 x = (u32)__builtin_ctz(tel), s0 = (u32)__builtin_ctz(tsl);
+                tel &= tel - 1;
+                tsl &= tsl - 1;
+                *slot++ = pos_lo(s0) | ((x - s0 + 1u) << 16);
+            }
+            if (tsl && teh && (!tsh || __builtin_ctz(teh) < __builtin_ctz(tsh))) {
+                const u32 x = 32u + (u32)__builtin_ctz(teh), s0 = (u32)__builtin_ctz(tsl);
+                teh &= teh - 1;
+                *slot++ = pos_lo(s0) | ((x - s0 + 1u) << 16);
+            }
+            while (teh) {
+                const u32 x = (u32)__builtin_ctz(teh), s0 = (u32)__builtin_ctz(tsh);
+                teh &= teh - 1;
+                tsh &= tsh - 1;
+                *slot++ = pos_hi(s0) | ((x - s0 + 1u) << 16);
+            }
+        } else {
+            while (te) {
+                int s0 = ctz(ts), x = ctz(te);
+                ts &= ts - 1;
+                te &= te - 1;
+                put(idx, outpos(s0), (u32)(x - s0 + 1), true);
+                idx++;
+            }
         }
     }
     __syncthreads();
@@ -1597,6 +1553,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
         const bool starts_inside_token = (sh.flags & 1) != 0;
         u32 n_ss = sh.total.nte - ((starts_inside_token && sh.total.nte > 0) ? 1u : 0u);
         if (n_ss > TOK_CAP) n_ss = TOK_CAP;
+        if (stop_after == 6) n_ss = 0;   // profiling aid: everything but the token table stores
         for (u32 i = tid; i < n_ss; i += NT) {
             u32 v = tokstage[i];
             tok_start[tok0 + i] = out0 + (v & 0xFFFFu);

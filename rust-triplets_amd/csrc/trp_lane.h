@@ -829,11 +829,9 @@ TRP_HD TokInfo next_token(ByteSrc& s, u64 pos, u64 end, bool table, const UniTab
 // Calls f(token, keep) for every token of the line [p, e) in order.  Pass K = ~0 to get the digit
 // sum / count of the tokens at distance exactly `probe` instead (no callback use).
 template <class F>
-TRP_HD void g3_walk(ByteSrc& s, u64 p, u64 e, bool table, const UniTables& ut, u64 K, u64 probe,
-                    u64* wave_digits, u64* wave_count, F f) {
+TRP_HD void g3_walk(ByteSrc& s, u64 p, u64 e, bool table, const UniTables& ut, F f) {
     u64 pos = p;
     bool left_alpha = false;
-    u64 wd = 0, wc = 0;
     for (;;) {
         // first walk: length of the gap and what closes it
         u64 g = 0, q = pos;
@@ -846,58 +844,48 @@ TRP_HD void g3_walk(ByteSrc& s, u64 p, u64 e, bool table, const UniTables& ut, u
             g++;
             q = closer.te;
         }
-        // second walk: every gap token with its distance
+        // second walk: every gap token with its distance to the nearest token that has a letter
         q = pos;
         for (u64 i = 1; i <= g; i++) {
             TokInfo t = next_token(s, q, e, table, ut);
             q = t.te;
             u64 df = left_alpha ? i : ~0ull;
             u64 db = right_alpha ? g + 1 - i : ~0ull;
-            u64 dist = df < db ? df : db;
-            if (dist == probe) { wd += t.digits; wc++; }
-            f(t, dist <= K);
+            f(t, df < db ? df : db);
         }
         if (!right_alpha) break;
-        f(closer, true);
+        f(closer, 0ull);
         left_alpha = true;
         pos = closer.te;
     }
-    if (wave_digits) *wave_digits = wd;
-    if (wave_count) *wave_count = wc;
 }
 
-struct NoTok {
-    TRP_HD void operator()(const TokInfo&, bool) const {}
-};
-
-// Number of accepted waves for the line [p, e).
+// Number of accepted waves for the line [p, e) (denoiser_preprocessor.rs:94-131).  The digits of the
+// tokens at each distance are gathered for G3_WINDOW distances per walk over the line.
+constexpr int G3_WINDOW = 32;
 TRP_HD u64 g3_solve_K(ByteSrc& s, u64 p, u64 e, bool table, float max_ratio, const UniTables& ut) {
-    // seed totals: digits and alphabetic chars of the alphabetic-bearing tokens
-    u64 d = 0, a = 0;
-    {
-        u64 pos = p;
-        int len;
-        for (;;) {
-            TokInfo t = next_token(s, pos, e, table, ut);
-            if (t.te == t.ts) break;
-            if (t.alpha) {
+    u64 d = 0, a = 0, K = 0;
+    for (u64 k0 = 0;; k0 += G3_WINDOW) {
+        u64 hd[G3_WINDOW], hc[G3_WINDOW];
+        for (int i = 0; i < G3_WINDOW; i++) hd[i] = hc[i] = 0;
+        g3_walk(s, p, e, table, ut, [&](const TokInfo& t, u64 dist) {
+            if (dist == 0 && k0 == 0) {   // seed: digits and letters of the tokens that have a letter
                 d += t.digits;
+                int len;
                 for (u64 q = t.ts; q < t.te; q += len)
                     if (char_at(s, q, t.te, &len, ut) & C_ALPHA) a++;
+            } else if (dist >= k0 && dist < k0 + G3_WINDOW) {
+                hd[dist - k0] += t.digits;
+                hc[dist - k0]++;
             }
-            pos = t.te;
+        });
+        for (int i = (k0 == 0 ? 1 : 0); i < G3_WINDOW; i++) {
+            if (hc[i] == 0) return K;
+            if (ratio_exceeds64(d + hd[i], a, max_ratio)) return K;
+            d += hd[i];
+            K = k0 + (u64)i;
         }
     }
-    u64 K = 0;
-    for (u64 k = 1;; k++) {
-        u64 wd, wc;
-        g3_walk(s, p, e, table, ut, 0, k, &wd, &wc, NoTok());
-        if (wc == 0) break;
-        if (ratio_exceeds64(d + wd, a, max_ratio)) break;
-        d += wd;
-        K = k;
-    }
-    return K;
 }
 
 }  // namespace trp

@@ -212,9 +212,9 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                 u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
                 pb.clear_marker(p);
                 bool first = true;
-                g3_walk(src, p, e, table, ut, K, ~0ull - 1, nullptr, nullptr,
-                        [&](const TokInfo& t, bool keep) {
-                            if (!keep) return;
+                g3_walk(src, p, e, table, ut,
+                        [&](const TokInfo& t, u64 dist) {
+                            if (dist > K) return;
                             for (u64 q = t.ts; q < t.te; q++)
                                 pb.set(q, true, true, q == t.ts ? (first ? (rab ? 2 : 0) : 1) : 0);
                             first = false;

@@ -266,12 +266,13 @@ class DeviceResult:
         for name, _ in _Result._fields_:
             setattr(self, name, getattr(res, name) or 0)
 
-    def fetch(self, name, count, dtype):
+    def fetch(self, name, count, dtype, offset=0):
+        """Copy `count` elements of the device array `name`, starting at element `offset`, to the host."""
         dtype = np.dtype(dtype)
         out = np.empty(int(count), dtype=dtype)
         if count:
-            _check(load_library().trp_copy_to_host(self.ctx._h, out.ctypes.data, getattr(self, name),
-                                                   out.nbytes))
+            _check(load_library().trp_copy_to_host(self.ctx._h, out.ctypes.data,
+                                                   getattr(self, name) + int(offset) * dtype.itemsize, out.nbytes))
         return out
 
     def to_host(self, denoised_from=None) -> BatchResult:

@@ -154,3 +154,46 @@ def test_config_d_skewed_two_overlaps():
     data, offs = corpusgen.config_d(SIZE, 44, 16)
     res = check_batch("config D", data, offs, (64, 256))
     assert res.n_chunks > len(offs) - 1      # the 1 MiB records have many windows
+
+
+def test_config_c_full_size_four_gigabytes():
+    """BASELINE config C at its full 4.0e9 bytes (close to the 4 GiB batch limit): totals, monotone
+    offsets and exact agreement with the oracle on record ranges at the start, around the 2^31 and 3e9
+    byte marks and at the end."""
+    import corpusgen
+    import torch
+    if SIZE < 1_000_000_000:
+        pytest.skip("reduced-size run")
+    data, offs = corpusgen.config_c(4_000_000_000, 43, 16)
+    R, N = len(offs) - 1, int(offs[-1])
+    assert N > 3_900_000_000
+    den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy()
+    ocfg = O.make_config(True, 0.35, True, 1024, (64,), 512)
+    ctx = T.Context(0)
+    d_bytes = torch.from_numpy(data).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    dev = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
+    doff = dev.fetch("denoised_offsets", R + 1, np.uint64)
+    toff = dev.fetch("tok_offsets", R + 1, np.uint64)
+    coff = dev.fetch("chunk_offsets", R + 1, np.uint64)
+    for a, total in ((doff, dev.n_denoised), (toff, dev.n_tokens), (coff, dev.n_chunks)):
+        assert a[0] == 0 and int(a[-1]) == int(total) and np.all(a[1:] >= a[:-1])
+    assert int(dev.n_denoised) <= N
+    for mark in (0, 2**31 - 3_000_000, 3_000_000_000, N - 6_000_000):
+        a = int(np.searchsorted(offs, np.uint64(mark), side="left"))
+        b = int(np.searchsorted(offs, np.uint64(min(N, mark + 6_000_000)), side="left"))
+        a, b = min(a, R - 1), max(min(b, R), min(a, R - 1) + 1)
+        d, o = T.shard_slice(data, offs, a, b)
+        exp = O.batch(d, o, ocfg, n_threads=8)
+        d0, t0, c0 = int(doff[a]), int(toff[a]), int(coff[a])
+        ch = dev.fetch("chunks", int(coff[b]) - c0, T.CHUNK_DTYPE, c0)
+        ch["record"] -= np.uint32(a)
+        got = T.BatchResult(
+            denoised=dev.fetch("denoised", int(doff[b]) - d0, np.uint8, d0), denoised_offsets=doff[a:b + 1] - np.uint64(d0),
+            dropped=dev.fetch("dropped", b - a, np.uint8, a),
+            tok_start=(dev.fetch("tok_start", int(toff[b]) - t0, np.uint32, t0).astype(np.int64) - d0).astype(np.uint32),
+            tok_len=dev.fetch("tok_len", int(toff[b]) - t0, np.uint32, t0), tok_offsets=toff[a:b + 1] - np.uint64(t0),
+            chunks=ch, chunk_offsets=coff[a:b + 1] - np.uint64(c0), n_records=b - a, n_denoised=int(doff[b]) - d0,
+            n_tokens=int(toff[b]) - t0, n_chunks=int(coff[b]) - c0)
+        assert_same(exp, got, None, "config C 4e9 records [%d,%d)" % (a, b))
+    ctx.close()

@@ -143,11 +143,31 @@ def test_edge_batches(T, ctx):
 
 def test_many_digit_heavy_lines_grow_the_work_list(T, ctx):
     """more gate-3 lines than the optimistic work list holds: the batch is re-run with the exact size"""
-    recs = [b"12 ab 34\n" * 20000, b"7 x 9 9\n| 5 | y | 77 |\n" * 15000, b"plain words only\n" * 10]
+    # lines of 71 tokens do not fit the in-tile solver (64 tokens) and are short enough to outnumber the
+    # list's first capacity of one entry per 256 bytes
+    recs = [b"12 ab 34\n" * 20000, (b"1 " * 70 + b"a\n") * 20000, b"7 x 9 9\n| 5 | y | 77 |\n" * 15000,
+            b"plain words only\n" * 10]
     exp, got = _run(T, ctx, recs, (True, 0.35, True, 64, (8,), 16))
     assert_same(exp, got, recs, "g3list")
     exp, got = _run(T, ctx, recs, (True, 0.35, True, 64, (8,), 16))   # second call: buffer already large
     assert_same(exp, got, recs, "g3list2")
+
+
+def test_extreme_record_counts_and_line_lengths(T, ctx):
+    # two million empty records around a few real ones
+    recs = [b""] * 1_000_000 + [b"alpha 1 2 3\nbeta"] + [b""] * 1_000_000 + [b"| x | 1 |", b""]
+    exp, got = _run(T, ctx, recs, (True, 0.35, True, 4, (1,), 2))
+    assert_same(exp, got, None, "empty records")
+    exp, got = _run(T, ctx, recs, (False, 0.35, True, 4, (1,), 2))
+    assert_same(exp, got, None, "empty records, pass-through")
+    # one digit-heavy line of 300 KB (serial solver, 19 tiles), a kept and a dropped line of 3 MB, a long
+    # table row; the higher ratios make the expansion run for tens of waves (more than one window of the
+    # serial solver's distance histogram)
+    recs = [b"word " + b"12345 " * 50_000 + b"tail", b"letters " * 400_000, b"0123456789 " * 300_000,
+            (b"| " + b"9 | " * 20_000 + b"z |"), b"ab " * 10 + b"1 " * 3000 + b"cd " * 10]
+    for ratio in (0.35, 0.9, 0.97):
+        exp, got = _run(T, ctx, recs, (True, ratio, True, 1024, (64,), 512))
+        assert_same(exp, got, None, "long lines ratio %s" % ratio)
 
 
 def test_long_records_and_multiple_overlaps(T, ctx):

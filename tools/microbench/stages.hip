@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NT) void k_exp(const u8* __restrict__ bytes, const 
     }
     if (STAGE == 5) {   // check the ballot formulation against the ordered fold
         J a = wave_reduce_ordered(j, JOp());
-        J w = wave_J(j);
+        J w = wave_total(wave_lines(j));
         if ((threadIdx.x & 63) == 0) {
             bool same = a.g == w.g && a.head.d == w.head.d && a.head.a == w.head.a && a.head.p == w.head.p &&
                         a.head.f == w.head.f;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NT) void k_exp(const u8* __restrict__ bytes, const 
         }
         return;
     }
-    j = STAGE == 4 ? wave_J(j) : wave_reduce_ordered(j, JOp());
+    j = STAGE == 4 ? wave_total(wave_lines(j)) : wave_reduce_ordered(j, JOp());
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -130,7 +130,7 @@ int main() {
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        const char* nm[] = {"stage + lane word reads", "+ classify", "+ derive", "+ lane_J", "+ ballot wave_J + store", "check wave_J == fold", "+ shuffle fold + store (old)", "check carries"};
+        const char* nm[] = {"stage + lane word reads", "+ classify", "+ derive", "+ lane_J", "+ prefix-sum wave total + store", "check wave total == fold", "+ shuffle fold + store (old)", "check carries"};
         printf("%-34s %.3f ms\n", nm[s], best);
     }
     u32 hs[4] = {0, 0, 0, 0};
