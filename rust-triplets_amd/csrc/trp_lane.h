@@ -296,14 +296,30 @@ TRP_UNROLL
     const u64 high = b[7] & V;
     u64 lead = high & b[6];
     while (lead) {
-        int j = ctz(lead);
+        const int j = ctz(lead);
         lead &= lead - 1;
-        u32 cp;
-        int n = decode_lead(blk, j, &cp);
-        if (n) {
-            if (cp_is_ws_high(cp)) c.ws |= below(j + n) & ~below(j) & V;
+        // straight-line decode by sequence length (same acceptance rules as decode_lead); only the lead
+        // bytes C2, E1, E2, E3 can begin a whitespace character
+        const u32 b0 = blk[j], b1 = blk[j + 1];
+        if ((b1 & 0xC0u) != 0x80u) continue;
+        if (b0 < 0xE0u) {
+            const u32 cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+            if (cp == 0x85u || cp == 0xA0u) c.ws |= (3ull << j) & V;
             else if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
+            continue;
         }
+        const u32 b2 = blk[j + 2];
+        if ((b2 & 0xC0u) != 0x80u) continue;
+        if (b0 < 0xF0u) {
+            const u32 cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+            if (b0 <= 0xE3u && b0 != 0xE0u && cp_is_ws_high(cp)) c.ws |= (7ull << j) & V;
+            else if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
+            continue;
+        }
+        const u32 b3 = blk[j + 3];
+        if ((b3 & 0xC0u) != 0x80u) continue;
+        const u32 cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+        if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
     }
     u64 head = high & ~b[6] & 7ull;   // continuation bytes among the first three
     for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
