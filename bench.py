@@ -69,10 +69,17 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
-    torch.cuda.set_device(local_rank)
+    # Rehearsal aids (never set by the driver): TRP_BENCH_DEVICE pins every rank to one GPU and
+    # TRP_BENCH_BACKEND=gloo replaces RCCL, so that the multi-rank code path can run on a one-GPU box.
+    device = int(os.environ.get("TRP_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("TRP_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic batch for this rank (shard = its own record range of the corpus) -----------------
     threads = max(1, 16 // max(1, world))
@@ -95,7 +102,7 @@ def main():
 
     den = T.DenoiserConfig(enabled=not args.no_denoise, max_digit_ratio=0.35, strip_markdown=True)
     st = T.ChunkingStrategy()   # reference defaults: 1024 / [64] / 512
-    ctx = T.Context(local_rank)
+    ctx = T.Context(device)
 
     def step():
         if args.normalize:
@@ -150,11 +157,18 @@ def main():
                 "path_algorithmic_bytes": path_algorithmic_bytes(stats),
                 "path_frac": round(path_algorithmic_bytes(stats) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
+    # HBM bytes per launch of the dominant kernel from the committed counter runs (tools/collect_profiles.sh),
+    # used only when they were taken on this very workload
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
         try:
             with open(tr) as f:
-                roofline["traffic"] = (json.load(f).get(dominant) or {}).get("bytes")
+                tj = json.load(f)
+            meta = tj.get("_meta", {})
+            same = (meta.get("bytes_per_gpu") == N and meta.get("workload") == workload
+                    and meta.get("denoiser") == ("enabled" if den.enabled else "disabled") and not args.normalize)
+            if same:
+                roofline["traffic"] = (tj.get(dominant) or {}).get("bytes")
         except Exception:
             pass
 

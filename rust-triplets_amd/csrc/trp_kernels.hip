@@ -125,27 +125,6 @@ __device__ inline T block_scan_excl_fwd(T v, Op op, T identity, T seed, T* smem,
     return res;
 }
 
-// Exclusive backward scan: thread i receives op(v[i+1], ..., v[NT-1], seed).
-template <class T, class Op>
-__device__ inline T block_scan_excl_bwd(T v, Op op, T identity, T seed, T* smem) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        T o = shfl_down_pod(inc, off);
-        if (lane + off < 64) inc = op(inc, o);
-    }
-    if (lane == 0) smem[wave] = inc;
-    __syncthreads();
-    T post = seed;
-    for (int w = NT / 64 - 1; w > wave; w--) post = op(smem[w], post);
-    T ex = shfl_down_pod(inc, 1);
-    if (lane == 63) ex = identity;
-    T res = op(ex, post);
-    __syncthreads();
-    return res;
-}
-
 __device__ inline u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
 
 // ---- line carries of a tile from wave prefix sums and ballots ----------------------------------------

@@ -18,4 +18,13 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/fetch" -o fetch -
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/write" -o write -- \
     python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/write.json" 2> "$OUT/write.log"
 python3 tools/pmc_summary.py --traffic "$OUT/fetch" "$OUT/write" "$OUT/traffic.json" > "$OUT/traffic.txt"
+python3 - "$OUT" <<'PY'
+import json, sys
+out = sys.argv[1]
+t = json.load(open(out + "/traffic.json"))
+b = json.load(open(out + "/bench.json"))
+t["_meta"] = {"bytes_per_gpu": b["config"]["bytes_per_gpu"], "workload": b["config"]["workload"],
+              "denoiser": b["config"]["denoiser"]}
+json.dump(t, open(out + "/traffic.json", "w"), indent=1, sort_keys=True)
+PY
 cat "$OUT/traffic.txt"

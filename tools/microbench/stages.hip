@@ -41,28 +41,6 @@ __global__ __launch_bounds__(NT) void k_exp(const u8* __restrict__ bytes, const 
         if (x == 0x12345u) sink[0] = x;
         return;
     }
-    if (STAGE == 7) {   // check the prefix-sum / ballot carries against the shuffle scans
-        __shared__ J jscan[NT / 64];
-        __shared__ S sscan[NT / 64];
-        __shared__ J wt[NT / 64];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        J P = block_scan_excl_fwd(j, JOp(), j_identity(), j_identity(), jscan, (J*)nullptr);
-        S X = block_scan_excl_bwd(s_from_J(j), SOp(), s_identity(), s_identity(), sscan);
-        LaneCarry a = carry_from(P, X, L.next_rs);
-        const WaveLines W = wave_lines(j);
-        { const J t2 = wave_total(W); if (lane == 0) wt[wave] = t2; }
-        __syncthreads();
-        J Pw = j_identity();
-        for (int w = 0; w < wave; w++) Pw = j_combine(Pw, wt[w]);
-        S Xw = s_identity();
-        for (int w = NT / 64 - 1; w > wave; w--) Xw = s_combine(s_from_J(wt[w]), Xw);
-        LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
-        bool same = a.ci.d == k.ci.d && a.ci.a == k.ci.a && a.ci.p == k.ci.p && a.ci.f == k.ci.f &&
-                    a.co.d == k.co.d && a.co.a == k.co.a && a.co.p == k.co.p && a.co.f == k.co.f &&
-                    a.ci_rab == k.ci_rab && a.ar_in == k.ar_in;
-        if (!same) atomicAdd(&sink[3], 1u);
-        return;
-    }
     if (STAGE == 5) {   // check the ballot formulation against the ordered fold
         J a = wave_reduce_ordered(j, JOp());
         J w = wave_total(wave_lines(j));
@@ -112,7 +90,7 @@ int main() {
     (void)hipMemcpy(d, h.data(), N, hipMemcpyHostToDevice);
     (void)hipMemcpy(rs, hrs.data(), (nB + 2) * 8, hipMemcpyHostToDevice); (void)hipMemset(sink, 0, 64);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int s = 0; s <= 7; s++) {
+    for (int s = 0; s <= 6; s++) {
         float best = 1e9;
         for (int r = 0; r < 5; r++) {
             (void)hipEventRecord(e0);
@@ -123,18 +101,17 @@ int main() {
                 case 3: hipLaunchKernelGGL(k_exp<3>, dim3(nT), dim3(NT), 0, 0, d, rs, N, nB, sa, sink); break;
                 case 4: hipLaunchKernelGGL(k_exp<4>, dim3(nT), dim3(NT), 0, 0, d, rs, N, nB, sa, sink); break;
                 case 5: hipLaunchKernelGGL(k_exp<5>, dim3(nT), dim3(NT), 0, 0, d, rs, N, nB, sa, sink); break;
-                case 7: hipLaunchKernelGGL(k_exp<7>, dim3(nT), dim3(NT), 0, 0, d, rs, N, nB, sa, sink); break;
                 default: hipLaunchKernelGGL(k_exp<6>, dim3(nT), dim3(NT), 0, 0, d, rs, N, nB, sa, sink); break;
             }
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        const char* nm[] = {"stage + lane word reads", "+ classify", "+ derive", "+ lane_J", "+ prefix-sum wave total + store", "check wave total == fold", "+ shuffle fold + store (old)", "check carries"};
+        const char* nm[] = {"stage + lane word reads", "+ classify", "+ derive", "+ lane_J", "+ prefix-sum wave total + store", "check wave total == fold", "+ shuffle fold + store (old)"};
         printf("%-34s %.3f ms\n", nm[s], best);
     }
     u32 hs[4] = {0, 0, 0, 0};
     (void)hipMemcpy(hs, sink, 16, hipMemcpyDeviceToHost);
-    printf("wave_J check: %u mismatches in %u waves; carry check: %u mismatching lanes\n", hs[1], hs[2], hs[3]);
-    return hipDeviceSynchronize() == hipSuccess && hs[1] == 0 && hs[3] == 0 ? 0 : 1;
+    printf("wave total check: %u mismatches in %u waves\n", hs[1], hs[2]);
+    return hipDeviceSynchronize() == hipSuccess && hs[1] == 0 ? 0 : 1;
 }
