@@ -864,11 +864,14 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     // out for the four waves and selected field by field (keeps the summaries in registers)
     J Pw = sh.seed_j;
     S Xw = sh.seed_s;
+    {
+        const int wu = __builtin_amdgcn_readfirstlane(wave);   // scalar: the branches below are uniform
 #pragma unroll
-    for (int w = 0; w < NT / 64 - 1; w++) {
-        Pw = j_select(w < wave, j_combine(Pw, sh.jscan[w]), Pw);
-        const int v = NT / 64 - 1 - w;
-        Xw = s_select(v > wave, s_combine(s_from_J(sh.jscan[v]), Xw), Xw);
+        for (int w = 0; w < NT / 64 - 1; w++) {
+            if (w < wu) Pw = j_combine(Pw, sh.jscan[w]);
+            const int v = NT / 64 - 1 - w;
+            if (v > wu) Xw = s_combine(s_from_J(sh.jscan[v]), Xw);
+        }
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }

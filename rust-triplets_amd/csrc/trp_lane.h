@@ -601,23 +601,29 @@ TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
 
 TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg) {
     Plan out = {0, 0, 0, 0};
-    const u64 T = d.LC & ~c.ws & ~c.pipe;   // text bytes
-    const u64 W = d.LC & c.ws;              // whitespace inside lines
     const bool head0 = !(d.LS & 1ull);      // the block starts inside a line begun earlier
     // Cell trimming of table rows (strip_table_pipes): a whitespace byte survives only when the
-    // nearest non-whitespace byte on either side, within the line, is text (not a pipe).
-    const u64 cin_text = (head0 && ls_last(k.ci) == 2u) ? 1ull : 0ull;
-    const u64 Wp = W & ~d.LS;
-    const u64 SL = ((T << 1) | cin_text) & Wp;
-    const u64 LT = Wp & ~(Wp + SL);
-    const u64 Wq = W & ~((d.LS >> 1) | (k.next_rs ? bit(63) : 0ull));
-    const u64 cin_right = (ls_first(k.co) == 2u) ? bit(63) : 0ull;
-    const u64 SR = ((T >> 1) | cin_right) & Wq;
-    const u64 rW = brev(Wq), rS = brev(SR);
-    const u64 RT = brev(rW & ~(rW + rS));
-    const u64 IW = LT & RT;
-    const u64 prevtext = (((T | LT) << 1) | cin_text) & ~d.LS;
-    const u64 CS = T & ~prevtext;   // first byte of a trimmed cell
+    // nearest non-whitespace byte on either side, within the line, is text (not a pipe).  The masks are
+    // only needed by blocks that hold (part of) a table row and are computed on first use.
+    u64 T = 0, IW = 0, CS = 0;
+    bool have_table_masks = false;
+    auto table_masks = [&]() {
+        T = d.LC & ~c.ws & ~c.pipe;         // text bytes
+        const u64 W = d.LC & c.ws;          // whitespace inside lines
+        const u64 cin_text = (head0 && ls_last(k.ci) == 2u) ? 1ull : 0ull;
+        const u64 Wp = W & ~d.LS;
+        const u64 SL = ((T << 1) | cin_text) & Wp;
+        const u64 LT = Wp & ~(Wp + SL);
+        const u64 Wq = W & ~((d.LS >> 1) | (k.next_rs ? bit(63) : 0ull));
+        const u64 cin_right = (ls_first(k.co) == 2u) ? bit(63) : 0ull;
+        const u64 SR = ((T >> 1) | cin_right) & Wq;
+        const u64 rW = brev(Wq), rS = brev(SR);
+        const u64 RT = brev(rW & ~(rW + rS));
+        IW = LT & RT;
+        const u64 prevtext = (((T | LT) << 1) | cin_text) & ~d.LS;
+        CS = T & ~prevtext;                 // first byte of a trimmed cell
+        have_table_masks = true;
+    };
 
     int s = 0;
     bool is_head = head0;
@@ -650,6 +656,7 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
                     out.TOK |= d.LC & R & ~c.ws;
                     if (!is_head && rab) out.PNL |= bit(s);
                 } else {
+                    if (!have_table_masks) table_masks();
                     out.C |= R & (T | IW);
                     out.TOK |= R & T;
                     u64 cs = CS & R, Tr = T & R;

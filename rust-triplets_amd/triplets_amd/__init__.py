@@ -20,6 +20,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtriplets_amd.so")
+if os.environ.get("TRIPLETS_AMD_LIB"):   # another build of the same library (kernel experiments)
+    LIB_PATH = os.environ["TRIPLETS_AMD_LIB"]
 
 TRP_OK = 0
 
