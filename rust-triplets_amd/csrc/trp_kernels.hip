@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -247,20 +248,6 @@ __device__ inline LineSum ls_select(bool c, LineSum a, LineSum b) {
     LineSum r = {sel32(c, a.d, b.d), sel32(c, a.a, b.a), sel32(c, a.p, b.p), sel32(c, a.f, b.f)};
     return r;
 }
-__device__ inline J j_select(bool c, const J& a, const J& b) {
-    J r;
-    r.head = ls_select(c, a.head, b.head);
-    r.tail = ls_select(c, a.tail, b.tail);
-    r.g = c ? a.g : b.g;
-    return r;
-}
-__device__ inline S s_select(bool c, const S& a, const S& b) {
-    S r;
-    r.head = ls_select(c, a.head, b.head);
-    r.has_ls = c ? a.has_ls : b.has_ls;
-    return r;
-}
-
 // The lane's carries.  Pw = summary of everything before the wave back to the start of the record that
 // covers the wave's first byte, Xw = backward summary of what follows the wave (both uniform).
 __device__ inline LaneCarry wave_carry(const WaveLines& W, const J& Pw, const S& Xw, bool next_rs) {
@@ -1730,6 +1717,7 @@ struct trp_ctx {
     trp_result last = {};
     u64 last_R = 0;
     bool have_last = false;
+    trp_ctx* aux = nullptr;             // second set of buffers + stream for the pipelined host path
     // Profiling aid: with profiling on and TRP_PROFILE_EMIT_STOP=k (1..5) in the environment, k_emit ends
     // every tile after phase k, so that the phases can be timed one by one.  The results of such a call
     // are incomplete; calls without profiling are never affected.
@@ -1834,6 +1822,7 @@ int trp_create(int device, trp_ctx** out) {
 
 void trp_destroy(trp_ctx* c) {
     if (!c) return;
+    if (c->aux) { trp_destroy(c->aux); c->aux = nullptr; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->rec_lo, &c->rsmap, &c->SA, &c->seedJ, &c->seedS, &c->plan,
@@ -1861,6 +1850,22 @@ int trp_get_profile(trp_ctx* c, trp_kernel_time* out, int cap) {
     for (int i = 0; i < n && i < cap; i++) out[i] = c->last_profile[i];
     return n;
 }
+
+namespace {
+// Shift the result arrays of one sub-batch to their place in the whole batch (pipelined host path).
+__global__ void k_add_u32(u32* __restrict__ a, u64 n, u32 add) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += add;
+}
+__global__ void k_add_u64(u64* __restrict__ a, u64 n, u64 add) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += add;
+}
+__global__ void k_add_chunk_record(ChunkDesc* __restrict__ c, u64 n, u32 add) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i].record += add;
+}
+}  // namespace
 
 static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
                       const DevCfg& dc, trp_result* out) {
@@ -2171,6 +2176,140 @@ void trp_free(void* p) { host_pool().release(p); }
 
 void trp_trim_host_pool(void) { host_pool().trim(); }
 
+// Host batch in sub-batches of consecutive records, alternating between two sets of device buffers and two
+// streams: while the results of one sub-batch travel to the host, the text of the next travels to the
+// device (the two directions of the link run concurrently; the kernels are a small fraction of the time).
+// The result is assembled in place: every sub-batch's arrays are shifted on the device and copied straight
+// to their final position in the (page-locked) result arrays.
+constexpr u64 PIPE_SUB_BYTES = 96ull << 20;
+constexpr u64 PIPE_MIN_BYTES = 256ull << 20;
+
+static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
+                              trp_result* out) {
+    const u64 N = offsets[R];
+    int rc;
+    if (!c->aux && (rc = trp_create(c->device, &c->aux))) return rc;
+    trp_ctx* cx[2] = {c, c->aux};
+    // sub-batch boundaries: first record at or after each multiple of the sub-batch size
+    std::vector<u64> cut(1, 0);
+    for (u64 target = PIPE_SUB_BYTES; target < N; target += PIPE_SUB_BYTES) {
+        u64 r = (u64)(std::lower_bound(offsets, offsets + R, target) - offsets);
+        if (r > cut.back() && r < R) cut.push_back(r);
+    }
+    cut.push_back(R);
+    const size_t S = cut.size() - 1;
+    u64 max_bytes = 0, max_recs = 0;
+    for (size_t i = 0; i < S; i++) {
+        max_bytes = std::max(max_bytes, offsets[cut[i + 1]] - offsets[cut[i]]);
+        max_recs = std::max(max_recs, cut[i + 1] - cut[i]);
+    }
+    for (trp_ctx* x : cx) {
+        if ((rc = x->in_bytes.ensure(max_bytes + 64))) return rc;
+        if ((rc = x->in_offsets.ensure((max_recs + 1) * sizeof(u64)))) return rc;
+    }
+    std::vector<u64> rebased[2];
+    auto send = [&](size_t i) -> int {   // text and offsets of sub-batch i to its device buffers (asynchronous)
+        trp_ctx* x = cx[i & 1];
+        const u64 r0 = cut[i], r1 = cut[i + 1], b0 = offsets[r0], nb = offsets[r1] - b0;
+        std::vector<u64>& rb = rebased[i & 1];
+        rb.resize(r1 - r0 + 1);
+        for (u64 j = 0; j <= r1 - r0; j++) rb[j] = offsets[r0 + j] - b0;
+        if (nb) HIPCHK(hipMemcpyAsync(x->in_bytes.p, bytes + b0, nb, hipMemcpyHostToDevice, x->stream));
+        HIPCHK(hipMemcpyAsync(x->in_offsets.p, rb.data(), rb.size() * sizeof(u64), hipMemcpyHostToDevice, x->stream));
+        return TRP_OK;
+    };
+
+    memset(out, 0, sizeof(*out));
+    HostPool& hp = host_pool();
+    u64 cap_den = 0, cap_tok = 0, cap_ch = 0;          // capacities of the three data-dependent arrays
+    u64 base_d = 0, base_t = 0, base_c = 0;
+    auto fail_free = [&](int code) { trp_result_free(out); return code; };
+    auto sync_all = [&]() -> int {
+        for (trp_ctx* x : cx) HIPCHK(hipStreamSynchronize(x->stream));
+        return TRP_OK;
+    };
+    // grow one array to hold `need` elements (rare: only when the first sub-batch under-estimated the rest)
+    auto grow = [&](void** p, u64* cap, u64 need, u64 used, size_t elem) -> int {
+        if (need <= *cap) return TRP_OK;
+        int r2 = sync_all();
+        if (r2) return r2;
+        const u64 ncap = need + need / 2 + 1024;
+        void* q = hp.alloc(ncap * elem);
+        if (!q) return fail(TRP_E_ARG, "out of host memory");
+        if (*p && used) memcpy(q, *p, used * elem);
+        hp.release(*p);
+        *p = q;
+        *cap = ncap;
+        return TRP_OK;
+    };
+    out->denoised_offsets = (u64*)hp.alloc((R + 1) * sizeof(u64));
+    out->tok_offsets = (u64*)hp.alloc((R + 1) * sizeof(u64));
+    out->chunk_offsets = (u64*)hp.alloc((R + 1) * sizeof(u64));
+    out->dropped = (u8*)hp.alloc(R ? R : 1);
+    if (!out->denoised_offsets || !out->tok_offsets || !out->chunk_offsets || !out->dropped)
+        return fail_free(fail(TRP_E_ARG, "out of host memory"));
+
+    if ((rc = send(0))) return fail_free(rc);
+    for (size_t i = 0; i < S; i++) {
+        trp_ctx* x = cx[i & 1];
+        const u64 r0 = cut[i], r1 = cut[i + 1], Rs = r1 - r0, Ns = offsets[r1] - offsets[r0];
+        if (i + 1 < S && (rc = send(i + 1))) return fail_free(rc);
+        trp_result d;
+        if ((rc = run_device(x, x->in_bytes.as<u8>(), x->in_offsets.as<u64>(), Rs, Ns, dc, &d))) return fail_free(rc);
+        if (i == 0) {   // size the result arrays from the first sub-batch's yield, with a margin
+            const double scale = Ns ? (double)N / (double)Ns * 1.08 : 1.0;
+            u64 want_d = std::min<u64>(N + 64, (u64)((double)d.n_denoised * scale) + (1u << 20));
+            if ((rc = grow((void**)&out->denoised, &cap_den, S == 1 ? d.n_denoised : want_d, 0, 1))) return fail_free(rc);
+            u64 want_t = (u64)((double)d.n_tokens * scale) + (1u << 18);
+            u64 tcap = 0;
+            if ((rc = grow((void**)&out->tok_start, &tcap, S == 1 ? d.n_tokens : want_t, 0, sizeof(u32)))) return fail_free(rc);
+            if ((rc = grow((void**)&out->tok_len, &cap_tok, S == 1 ? d.n_tokens : want_t, 0, sizeof(u32)))) return fail_free(rc);
+            u64 want_c = (u64)((double)d.n_chunks * scale) + R / 8 + 4096;
+            if ((rc = grow((void**)&out->chunks, &cap_ch, S == 1 ? d.n_chunks : want_c, 0, sizeof(trp_chunk)))) return fail_free(rc);
+        }
+        if (base_d + d.n_denoised > cap_den &&
+            (rc = grow((void**)&out->denoised, &cap_den, base_d + d.n_denoised, base_d, 1))) return fail_free(rc);
+        if (base_t + d.n_tokens > cap_tok) {
+            u64 tcap = cap_tok;
+            if ((rc = grow((void**)&out->tok_start, &tcap, base_t + d.n_tokens, base_t, sizeof(u32)))) return fail_free(rc);
+            if ((rc = grow((void**)&out->tok_len, &cap_tok, base_t + d.n_tokens, base_t, sizeof(u32)))) return fail_free(rc);
+        }
+        if (base_c + d.n_chunks > cap_ch &&
+            (rc = grow((void**)&out->chunks, &cap_ch, base_c + d.n_chunks, base_c, sizeof(trp_chunk)))) return fail_free(rc);
+        // shift on the device, then copy to the final position
+        hipStream_t st = x->stream;
+        auto blocks = [](u64 n) { return dim3((unsigned)((n + 255) / 256)); };
+        if (base_d && d.n_tokens) hipLaunchKernelGGL(k_add_u32, blocks(d.n_tokens), dim3(256), 0, st, d.tok_start, d.n_tokens, (u32)base_d);
+        if (base_d) hipLaunchKernelGGL(k_add_u64, blocks(Rs + 1), dim3(256), 0, st, d.denoised_offsets, Rs + 1, base_d);
+        if (base_t) hipLaunchKernelGGL(k_add_u64, blocks(Rs + 1), dim3(256), 0, st, d.tok_offsets, Rs + 1, base_t);
+        if (base_c) hipLaunchKernelGGL(k_add_u64, blocks(Rs + 1), dim3(256), 0, st, d.chunk_offsets, Rs + 1, base_c);
+        if (r0 && d.n_chunks)
+            hipLaunchKernelGGL(k_add_chunk_record, blocks(d.n_chunks), dim3(256), 0, st, reinterpret_cast<ChunkDesc*>(d.chunks),
+                               d.n_chunks, (u32)r0);
+        auto back = [&](void* dst, const void* src, size_t n) -> int {
+            if (n) HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st));
+            return TRP_OK;
+        };
+        if ((rc = back(out->denoised + base_d, d.denoised, d.n_denoised))) return fail_free(rc);
+        if ((rc = back(out->tok_start + base_t, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+        if ((rc = back(out->tok_len + base_t, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+        if ((rc = back(out->chunks + base_c, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
+        if ((rc = back(out->denoised_offsets + r0, d.denoised_offsets, (Rs + 1) * sizeof(u64)))) return fail_free(rc);
+        if ((rc = back(out->tok_offsets + r0, d.tok_offsets, (Rs + 1) * sizeof(u64)))) return fail_free(rc);
+        if ((rc = back(out->chunk_offsets + r0, d.chunk_offsets, (Rs + 1) * sizeof(u64)))) return fail_free(rc);
+        if ((rc = back(out->dropped + r0, d.dropped, Rs))) return fail_free(rc);
+        base_d += d.n_denoised;
+        base_t += d.n_tokens;
+        base_c += d.n_chunks;
+    }
+    if ((rc = sync_all())) return fail_free(rc);
+    out->n_records = R;
+    out->n_denoised = base_d;
+    out->n_tokens = base_t;
+    out->n_chunks = base_c;
+    return TRP_OK;
+}
+
 static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
                     trp_result* out) {
     if (!c || !out || !offsets) return fail(TRP_E_ARG, "null argument");
@@ -2178,6 +2317,12 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
     const u64 N = offsets[R];
     if (N && !bytes) return fail(TRP_E_ARG, "bytes is null");
     HIPCHK(hipSetDevice(c->device));
+    if (N > TRP_MAX_BATCH_BYTES || R >= 0xFFFFFFFEull) return fail(TRP_E_TOO_LARGE, "batch too large: split it by record range");
+    for (u64 r = 0; r < R; r++)
+        if (offsets[r + 1] < offsets[r]) return fail(TRP_E_ARG, "offsets must be non-decreasing");
+    const char* no_pipe = getenv("TRP_NO_PIPELINE");
+    if (N >= PIPE_MIN_BYTES && R >= 2 && dc.denoise_enabled && !(no_pipe && atoi(no_pipe)))
+        return run_host_pipelined(c, bytes, offsets, R, dc, out);
     int rc;
     if ((rc = c->in_bytes.ensure(N + 64))) return rc;
     if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;

@@ -197,3 +197,23 @@ def test_config_c_full_size_four_gigabytes():
             n_tokens=int(toff[b]) - t0, n_chunks=int(coff[b]) - c0)
         assert_same(exp, got, None, "config C 4e9 records [%d,%d)" % (a, b))
     ctx.close()
+
+
+def test_host_path_pipelined_equals_single_shot():
+    """trp_preprocess_batch splits a large host batch into sub-batches that alternate between two sets of
+    device buffers; the assembled result must equal the one-shot result (TRP_NO_PIPELINE=1) exactly."""
+    import corpusgen
+    for name, gen in (("D", corpusgen.config_d), ("C", corpusgen.config_c)):
+        data, offs = gen(400_000_000, 7, 16)
+        den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy(1024, [64, 256], 0.35, 512)
+        ctx = T.Context(0)
+        os.environ["TRP_NO_PIPELINE"] = "1"
+        try:
+            one = ctx.preprocess_batch(data, offs, den, st)
+        finally:
+            del os.environ["TRP_NO_PIPELINE"]
+        piped = ctx.preprocess_batch(data, offs, den, st)
+        assert_same(one, piped, None, "pipelined host path, config " + name)
+        again = ctx.preprocess_batch(data, offs, den, st)      # buffers and pool blocks are reused
+        assert_same(one, again, None, "pipelined host path, second call, config " + name)
+        ctx.close()
