@@ -138,6 +138,16 @@ int trp_copy_to_host(trp_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int trp_materialize_chunk_text_device(trp_ctx* ctx, uint8_t** d_text, uint64_t** d_text_offsets,
                                       uint64_t* n_text_bytes);
 
+/* "First k tokens" text of every record of the last device-resident batch: the record's preprocessed text
+ * verbatim when it has at most max_tokens tokens, otherwise its first max_tokens tokens joined by one
+ * space.  This is the truncation rule the reference applies after the path: BM25 query capping
+ * (src/sampler/backends/bm25_backend.rs:212-229), record_bm25_text (:503-532, over the text it assembled)
+ * and the body of a decorated chunk (src/sampler/mod.rs:1484-1497, with max_tokens = remaining budget).
+ * Produces device arrays like trp_materialize_chunk_text_device: text bytes and text_offsets[R+1].
+ * (The reference treats a limit of 0 as "no limit" at its call sites; here 0 selects no tokens.) */
+int trp_head_tokens_text_device(trp_ctx* ctx, uint32_t max_tokens, uint8_t** d_text,
+                                uint64_t** d_text_offsets, uint64_t* n_text_bytes);
+
 /* normalize_inline_whitespace (src/utils.rs:18-33) for every record of a batch: each run of White_Space
  * characters becomes one ' ' and the result is trimmed.  The File and CSV sources apply it to every text
  * they ingest (src/source/backends/file_source.rs:260, csv_source.rs:280-310), i.e. it is the step just

@@ -1605,9 +1605,23 @@ __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __res
 // ---------------------------------------------------------------------------------------------------
 // chunk text (optional): tokens joined by one space, or the record text for a single window
 // ---------------------------------------------------------------------------------------------------
+// A chunk is rendered as the record's text verbatim when it is the record's only window
+// (sliding_window.rs:43-58).  chunk_off == nullptr: "head" descriptors (k_head_desc), verbatim whenever
+// they cover all tokens of the record.
 __device__ inline bool chunk_is_whole_record(const ChunkDesc& c, const u64* chunk_off, const u64* tok_off) {
     u64 r = c.record;
-    return c.kind == 0 && chunk_off[r + 1] - chunk_off[r] == 1 && (u64)(c.tok_end - c.tok_begin) == tok_off[r + 1] - tok_off[r];
+    const bool all_tokens = (u64)(c.tok_end - c.tok_begin) == tok_off[r + 1] - tok_off[r];
+    if (!chunk_off) return all_tokens;
+    return c.kind == 0 && chunk_off[r + 1] - chunk_off[r] == 1 && all_tokens;
+}
+
+// One descriptor per record: its first min(T, k) tokens.
+__global__ void k_head_desc(const u64* __restrict__ tok_off, u64 R, u32 k, ChunkDesc* __restrict__ out) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const u64 T = tok_off[r + 1] - tok_off[r];
+    ChunkDesc d = {(u32)r, 0u, 0u, 0u, 0u, 0u, (u32)(T < (u64)k ? T : (u64)k), 0u};
+    out[r] = d;
 }
 
 // one wave per chunk
@@ -1709,6 +1723,7 @@ struct trp_ctx {
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
+    DevBuf heads;                       // head-of-record descriptors (trp_head_tokens_text_device)
     u64* h_totals = nullptr;            // pinned
     bool profiling = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
@@ -1829,7 +1844,7 @@ void trp_destroy(trp_ctx* c) {
                       &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
-                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len};
+                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads};
     for (DevBuf* b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     (void)hipStreamDestroy(c->stream);
@@ -2028,26 +2043,23 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     return TRP_OK;
 }
 
-int trp_materialize_chunk_text_device(trp_ctx* c, uint8_t** d_text, uint64_t** d_text_offsets, uint64_t* n_text_bytes) {
-    if (!c || !d_text || !d_text_offsets || !n_text_bytes) return fail(TRP_E_ARG, "null argument");
-    if (!c->have_last) return fail(TRP_E_ARG, "no device batch result to render");
-    HIPCHK(hipSetDevice(c->device));
+// Text of `C` descriptors over the last device batch: lengths, scan, emit.  chunk_off == nullptr for head
+// descriptors.
+static int render_text(trp_ctx* c, const ChunkDesc* chunks, u64 C, const u64* chunk_off, uint8_t** d_text,
+                       uint64_t** d_text_offsets, uint64_t* n_text_bytes) {
     const trp_result& L = c->last;
-    const u64 C = L.n_chunks, R = c->last_R;
     int rc;
     if ((rc = c->text_len.ensure((C + 1) * sizeof(u64)))) return rc;
     if ((rc = c->text_off.ensure((C + 2) * sizeof(u64)))) return rc;
-    const ChunkDesc* chunks = reinterpret_cast<const ChunkDesc*>(L.chunks);
-    (void)R;
     if (C) hipLaunchKernelGGL(k_chunk_text_len, dim3((unsigned)((C * 64 + NT - 1) / NT)), dim3(NT), 0, c->stream, chunks, C,
-                              L.chunk_offsets, L.tok_offsets, L.denoised_offsets, L.tok_len, c->text_len.as<u64>());
+                              chunk_off, L.tok_offsets, L.denoised_offsets, L.tok_len, c->text_len.as<u64>());
     if ((rc = scan_u64(c, c->text_len.as<u64>(), C, c->text_off.as<u64>()))) return rc;
     HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->text_off.as<u64>() + C, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     u64 nbytes = c->h_totals[4];
     if ((rc = c->text.ensure(nbytes + 16))) return rc;
     if (C) hipLaunchKernelGGL(k_chunk_text_emit, dim3((unsigned)((C * 64 + NT - 1) / NT)), dim3(NT), 0, c->stream, chunks, C,
-                              L.chunk_offsets, L.tok_offsets, L.denoised_offsets, L.tok_start, L.tok_len, L.denoised,
+                              chunk_off, L.tok_offsets, L.denoised_offsets, L.tok_start, L.tok_len, L.denoised,
                               c->text_off.as<u64>(), c->text.as<u8>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2055,6 +2067,28 @@ int trp_materialize_chunk_text_device(trp_ctx* c, uint8_t** d_text, uint64_t** d
     *d_text_offsets = c->text_off.as<u64>();
     *n_text_bytes = nbytes;
     return TRP_OK;
+}
+
+int trp_materialize_chunk_text_device(trp_ctx* c, uint8_t** d_text, uint64_t** d_text_offsets, uint64_t* n_text_bytes) {
+    if (!c || !d_text || !d_text_offsets || !n_text_bytes) return fail(TRP_E_ARG, "null argument");
+    if (!c->have_last) return fail(TRP_E_ARG, "no device batch result to render");
+    HIPCHK(hipSetDevice(c->device));
+    const trp_result& L = c->last;
+    return render_text(c, reinterpret_cast<const ChunkDesc*>(L.chunks), L.n_chunks, L.chunk_offsets, d_text,
+                       d_text_offsets, n_text_bytes);
+}
+
+int trp_head_tokens_text_device(trp_ctx* c, uint32_t max_tokens, uint8_t** d_text, uint64_t** d_text_offsets,
+                                uint64_t* n_text_bytes) {
+    if (!c || !d_text || !d_text_offsets || !n_text_bytes) return fail(TRP_E_ARG, "null argument");
+    if (!c->have_last) return fail(TRP_E_ARG, "no device batch result to render");
+    HIPCHK(hipSetDevice(c->device));
+    const u64 R = c->last_R;
+    int rc;
+    if ((rc = c->heads.ensure((R + 1) * sizeof(ChunkDesc)))) return rc;
+    if (R) hipLaunchKernelGGL(k_head_desc, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, c->last.tok_offsets, R,
+                              max_tokens, c->heads.as<ChunkDesc>());
+    return render_text(c, c->heads.as<ChunkDesc>(), R, (const u64*)nullptr, d_text, d_text_offsets, n_text_bytes);
 }
 
 static DevCfg normalize_devcfg() {

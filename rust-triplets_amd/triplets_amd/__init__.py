@@ -62,7 +62,7 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_result_free", "trp_preprocess_batch_device", "trp_copy_to_host",
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
-           "trp_normalize_batch_device", "trp_normalize_inline_whitespace"]
+           "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device"]
 
 _lib = None
 
@@ -106,6 +106,8 @@ def load_library():
     L.trp_free.argtypes = [C.c_void_p]
     L.trp_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.trp_get_profile.argtypes = [C.c_void_p, C.POINTER(_KernelTime), C.c_int]
+    L.trp_head_tokens_text_device.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.trp_normalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Result)]
     L.trp_normalize_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                              C.POINTER(_Result)]
@@ -378,6 +380,13 @@ class Context:
         """Chunk texts of the last device batch -> (bytes array, offsets[n_chunks+1]) on the host."""
         t, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         _check(self._L.trp_materialize_chunk_text_device(self._h, C.byref(t), C.byref(o), C.byref(n)))
+        return t.value or 0, o.value or 0, int(n.value)
+
+    def head_tokens_text(self, max_tokens: int):
+        """First-k-tokens text of every record of the last device batch (verbatim when the record has at
+        most k tokens) -> (device text pointer, device offsets[R+1] pointer, byte count)."""
+        t, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.trp_head_tokens_text_device(self._h, int(max_tokens), C.byref(t), C.byref(o), C.byref(n)))
         return t.value or 0, o.value or 0, int(n.value)
 
     def set_profiling(self, on: bool):
