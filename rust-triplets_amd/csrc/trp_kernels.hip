@@ -1213,7 +1213,7 @@ struct EmitScan {
     u32 nb, ntk, nte;   // emitted bytes, token starts, token ends
     int lts;            // tile-relative byte position of the last token start so far, -1 none
 };
-constexpr u32 TOK_CAP = 2304;   // tokens per tile staged in LDS (9 KiB); the rest is stored directly
+constexpr u32 TOK_CAP = 9 * TILE_BLOCKS;   // tokens per tile staged in LDS (9 KiB at 256 blocks); the rest is stored directly
 struct EmitOp {
     __device__ EmitScan operator()(const EmitScan& a, const EmitScan& b) const {
         EmitScan r;
