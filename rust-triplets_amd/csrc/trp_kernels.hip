@@ -519,13 +519,44 @@ __device__ inline S tile_lookahead(const J* __restrict__ SA, u64 t, u64 nT) {
 
 // k_tile_carry: what enters tile t from the left (fold of the summaries back to the start of the
 // record that covers the tile's first byte) and from the right (rest of the line that leaves the tile).
+// Usually the neighbouring tiles settle both (a record start within the previous few tiles, a line start
+// in the next one): one thread per tile looks at most TC_NEAR tiles each way and lists the tiles that
+// need a longer walk; those are then folded by one wavefront each, 64 summaries at a time.
+constexpr int TC_NEAR = 4;
+__global__ void k_tile_carry_near(const J* __restrict__ SA, u64 nT, J* __restrict__ seedJ, S* __restrict__ seedS,
+                                  u32* __restrict__ far_list, u32* __restrict__ far_count) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nT) return;
+    J P = j_identity();
+    bool ok = false;
+    for (int step = 1; step <= TC_NEAR; step++) {
+        if (t < (u64)step) { ok = true; break; }
+        const J v = SA[t - step];
+        P = j_combine(v, P);
+        if (v.g & G_RS) { ok = true; break; }
+    }
+    S X = s_identity();
+    bool ok2 = false;
+    for (int step = 1; step <= TC_NEAR; step++) {
+        if (t + step >= nT) { ok2 = true; break; }
+        X = s_combine(X, s_from_J(SA[t + step]));
+        if (X.has_ls) { ok2 = true; break; }
+    }
+    if (ok && ok2) { seedJ[t] = P; seedS[t] = X; }
+    else far_list[atomicAdd(far_count, 1u)] = (u32)t;
+}
+
 __global__ __launch_bounds__(NT) void k_tile_carry(const J* __restrict__ SA, u64 nT, J* __restrict__ seedJ,
-                                                    S* __restrict__ seedS) {
-    const u64 t = (u64)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    if (t >= nT) return;   // whole wave
-    J P = tile_lookback(SA, t);
-    S X = tile_lookahead(SA, t, nT);
-    if ((threadIdx.x & 63) == 0) { seedJ[t] = P; seedS[t] = X; }
+                                                    S* __restrict__ seedS, const u32* __restrict__ far_list,
+                                                    const u32* __restrict__ far_count) {
+    const u32 n = *far_count;
+    const u32 nwaves = gridDim.x * (NT / 64);
+    for (u32 i = blockIdx.x * (NT / 64) + (threadIdx.x >> 6); i < n; i += nwaves) {   // whole waves
+        const u64 t = far_list[i];
+        J P = tile_lookback(SA, t);
+        S X = tile_lookahead(SA, t, nT);
+        if ((threadIdx.x & 63) == 0) { seedJ[t] = P; seedS[t] = X; }
+    }
 }
 
 // ---- digit-heavy lines solved inside the tile (one wavefront per line) ---------------------------
@@ -1723,6 +1754,7 @@ struct trp_ctx {
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
+    DevBuf far_list;                    // tiles whose carries need a long walk (k_tile_carry)
     DevBuf heads;                       // head-of-record descriptors (trp_head_tokens_text_device)
     u64* h_totals = nullptr;            // pinned
     bool profiling = false;
@@ -1844,7 +1876,7 @@ void trp_destroy(trp_ctx* c) {
                       &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
-                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads};
+                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list};
     for (DevBuf* b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     (void)hipStreamDestroy(c->stream);
@@ -1926,6 +1958,7 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
         if ((rc = c->denoised.ensure(N + 64))) return rc;
         if ((rc = c->seedJ.ensure((nT + 1) * sizeof(J)))) return rc;
         if ((rc = c->seedS.ensure((nT + 1) * sizeof(S)))) return rc;
+        if ((rc = c->far_list.ensure((nT + 1) * sizeof(u32)))) return rc;
         if ((rc = c->g3list.ensure(g3_cap * sizeof(u64)))) return rc;
     }
     hipStream_t st = c->stream;
@@ -1952,8 +1985,11 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
               hipLaunchKernelGGL(k_summary, dim3((unsigned)((nT + SUM_TPW - 1) / SUM_TPW)), dim3(NT), 0, st, d_bytes, rsmap, N, nB,
                                  nT, dc.normalize, SA); }
             { Prof pr(c, "k_tile_carry");
-              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)((nT + NT / 64 - 1) / (NT / 64))), dim3(NT), 0, st, SA, nT,
-                                 c->seedJ.as<J>(), c->seedS.as<S>()); }
+              u32* far_count = reinterpret_cast<u32*>(totals + 7);   // zeroed with the totals
+              hipLaunchKernelGGL(k_tile_carry_near, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, SA, nT,
+                                 c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count);
+              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 4096)), dim3(NT), 0, st,
+                                 SA, nT, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count); }
             { Prof pr(c, "k_plan");
               hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, c->seedJ.as<J>(),
                                  c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes, ttoks, tflags,
