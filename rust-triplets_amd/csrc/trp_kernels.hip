@@ -11,7 +11,7 @@
 //   denoised[D], tok_start[T], tok_len[T], *_offsets[R+1], chunks[C]   results
 //
 // Kernel sequence with the denoiser enabled:
-//   k_rec_lo, k_rsmap -> k_summary -> k_tile_carry -> k_plan -> k_gate3_solve -> k_pack_tiles -> scan(3) -> k_emit
+//   k_rec_lo -> k_summary -> k_tile_carry -> k_plan -> k_gate3_solve -> k_pack_tiles -> scan(3) -> k_emit
 //   -> k_finish
 //   -> k_chunk_count -> scan(3) -> k_chunk_emit
 // and with it disabled: k_rec_lo -> k_count_tokens -> k_pack_tiles -> scan(3) -> k_emit<passthrough> ...
@@ -351,24 +351,77 @@ __device__ inline void tile_store(const TileRegs& r, u8* sb) {
     if (tid == 0) lds_store16(sb + 48, r.halo);                                  // last 16 bytes of block -1
     else if (tid == 1) lds_store16(sb + (TILE_BLOCKS + 1) * PAD_STRIDE, r.halo);
 }
-// Copy the tile [tS, tS+TILE) plus HALO bytes on both sides into LDS (zeros outside the corpus).
-__device__ inline void stage_tile(const u8* __restrict__ g, u64 N, u64 tS, u8* sb) {
-    TileRegs r;
-    tile_load(g, N, tS, r);
-    tile_store(r, sb);
-}
-
 __device__ inline PadBlk lane_block(const TileShared& sh, int i) {
     PadBlk b = {sh.bytes + (i + 1) * PAD_STRIDE};
     return b;
 }
 
-// k_rsmap: record-start bit map of the corpus (one u64 per 64-byte block, zeroed beforehand).
-__global__ void k_rsmap(const u64* __restrict__ offsets, u64 R, u64 N, u64* __restrict__ rsmap) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    u64 p = offsets[r];
-    if (p < N) atomicOr(reinterpret_cast<unsigned long long*>(&rsmap[p >> 6]), 1ull << (p & 63));
+// Record starts of a tile, one bit per byte, built in LDS from the offsets array: records
+// [rec_lo[t], rec_lo[t+1]) start inside tile t.  w[i] covers block i of the tile; w[TILE_BLOCKS] bit 0
+// says whether the byte right after the tile starts a record.  Run by wave 0 only (LDS operations of one
+// wave complete in order: clear, then set), before the barrier that publishes the tile image.
+struct RsShared {
+    u64 w[TILE_BLOCKS + 1];
+};
+struct RsFetch {
+    u32 q;   // wave 0: start offset of record r0 + lane, r1 included (or ~0; a batch is shorter than 4 GiB)
+    u32 n;   // wave 0: r1 - r0
+};
+// Global loads of the record starts of tile t, issued together with the tile's bytes.  Returns r0.
+__device__ inline u32 rs_fetch(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 t,
+                               RsFetch& f) {
+    f.q = ~0u;
+    f.n = 0;
+    if (threadIdx.x >= 64) return 0;
+    const u32 r0 = rec_lo[t], r1 = rec_lo[t + 1];
+    const u64 r = (u64)r0 + threadIdx.x;
+    f.n = r1 - r0;
+    if (r <= r1 && r < R) f.q = (u32)offsets[r];
+    return r0;
+}
+// A start at tS + TILE (the byte after the tile) lands in bit 0 of the extra word.
+__device__ inline void rs_set(RsShared& rs, u64 q, u64 N, u64 tS) {
+    const u64 d = q - tS;
+    if (q < N && d <= (u64)TILE) atomicOr(reinterpret_cast<unsigned long long*>(&rs.w[d >> 6]), 1ull << (d & 63));
+}
+__device__ inline void rs_store(const RsFetch& f, const u64* __restrict__ offsets, const u32* __restrict__ rec_lo,
+                                u64 R, u64 N, u64 t, RsShared& rs) {
+    if (threadIdx.x >= 64) return;
+    const u64 tS = t * (u64)TILE;
+    for (int i = threadIdx.x; i <= TILE_BLOCKS; i += 64) rs.w[i] = 0;
+    if (f.q != ~0u) rs_set(rs, f.q, N, tS);
+    if (f.n >= 64) {   // crowded tile: the rest of its records
+        const u64 r0 = rec_lo[t], r1 = (u64)r0 + f.n;
+        for (u64 r = r0 + 64 + threadIdx.x; r <= r1 && r < R; r += 64) rs_set(rs, offsets[r], N, tS);
+    }
+}
+
+// Record starts inside the 64-byte block wb (wb < nB), straight from the offsets array (binary search; equal
+// offsets of empty records are skipped in one step); *next says whether the byte after the block starts
+// a record.  For the rare lines solved outside their tile.
+__device__ inline u64 block_record_starts(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
+                                          u64 N, u64 wb, bool* next) {
+    const u64 lo = wb * 64;
+    u64 a = rec_lo[wb / TILE_BLOCKS], b = rec_lo[wb / TILE_BLOCKS + 1];   // the block's tile narrows the search
+    while (a < b) {
+        const u64 m = (a + b) >> 1;
+        if (offsets[m] < lo) a = m + 1; else b = m;
+    }
+    u64 bits = 0;
+    *next = false;
+    while (a < R) {
+        const u64 q = offsets[a];
+        if (q >= N || q > lo + 64) break;
+        if (q == lo + 64) { *next = true; break; }
+        bits |= 1ull << (q - lo);
+        u64 x = a + 1, y = R;   // first index whose offset is larger
+        while (x < y) {
+            const u64 m = (x + y) >> 1;
+            if (offsets[m] <= q) x = m + 1; else y = m;
+        }
+        a = x;
+    }
+    return bits;
 }
 
 struct LaneCtx {
@@ -380,7 +433,7 @@ struct LaneCtx {
     bool prev_tok;  // normalize mode: the byte before the block is a token byte of the same record
 };
 
-// rs_here / rs_next: record-start words of this block and of the next one (rsmap has one spare word).
+// rs_here / rs_next: record-start words of this block and of the next one (RsShared).
 __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, u64 N, u64 tS, bool want_lines,
                                      u64 rs_here, u64 rs_next, bool normalize = false) {
     LaneCtx L;
@@ -432,16 +485,18 @@ __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, 
 // k_summary: per-tile forward summary (line statistics at the tile edges, record-level alpha flags).
 // ---------------------------------------------------------------------------------------------------
 constexpr int SUM_TPW = 1;   // consecutive tiles per workgroup (the next one is loaded during the current one)
-__global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
+__global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                                 const u32* __restrict__ rec_lo, u64 R, u64 N,
                                                  u64 nB, u64 nT, u32 normalize, J* __restrict__ SA) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ J wsum[NT / 64];
+    __shared__ RsShared rs;
     const u64 t0 = (u64)blockIdx.x * SUM_TPW;
     TileRegs regs;
+    RsFetch rf;
     tile_load(bytes, N, t0 * (u64)TILE, regs);
-    u64 b = t0 * (u64)TILE_BLOCKS + threadIdx.x;
-    u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    rs_fetch(offsets, rec_lo, R, t0, rf);
     stage_tables(uni);
 #pragma unroll 1
     for (int i = 0; i < SUM_TPW; i++) {
@@ -449,15 +504,14 @@ __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, co
         if (t >= nT) break;   // uniform
         const u64 tS = t * (u64)TILE;
         tile_store(regs, sh.bytes);
-        const u64 rs_h = rs_here, rs_n = rs_next;
+        rs_store(rf, offsets, rec_lo, R, N, t, rs);
         __syncthreads();
-        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs_h, rs_n, normalize != 0);
+        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs.w[threadIdx.x], rs.w[threadIdx.x + 1],
+                               normalize != 0);
         // the next tile's loads are issued after the register-hungry classification
         if (i + 1 < SUM_TPW && t + 1 < nT) {
             tile_load(bytes, N, tS + TILE, regs);
-            b += TILE_BLOCKS;
-            rs_here = b < nB ? rsmap[b] : 0;
-            rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+            rs_fetch(offsets, rec_lo, R, t + 1, rf);
         }
         J j = wave_total(wave_lines(lane_J(L.c, L.d)));
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
@@ -849,10 +903,12 @@ struct PlanShared {
     u32 nlist;
     u64 g3base;
     u32 red[3][NT / 64];
+    RsShared rs;
 };
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 
-__global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N, u64 nB,
+__global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
                                               Plan* __restrict__ plan, u64* __restrict__ g3list, u64 g3cap,
                                               u64* __restrict__ g3count,
@@ -863,14 +919,20 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
     const u64 b = t * (u64)TILE_BLOCKS + tid;
-    stage_tile(bytes, N, tS, sh.tile.bytes);
-    stage_tables(uni);
-    const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    {
+        TileRegs regs;
+        RsFetch rf;
+        tile_load(bytes, N, tS, regs);
+        rs_fetch(offsets, rec_lo, R, t, rf);
+        stage_tables(uni);
+        tile_store(regs, sh.tile.bytes);
+        rs_store(rf, offsets, rec_lo, R, N, t, sh.rs);
+    }
     if (tid == 0) sh.seed_j = seedJ[t];
     if (tid == 64) sh.seed_s = seedS[t];
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
-    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, rs_here, rs_next, cfg.normalize != 0);
+    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w[tid], sh.rs.w[tid + 1], cfg.normalize != 0);
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
     const WaveLines W = wave_lines(lane_J(L.c, L.d));
     {
@@ -979,21 +1041,28 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     }
 }
 
-__global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ rsmap, u64 N,
+__global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                                      const u32* __restrict__ rec_lo, u64 R, u64 N,
                                                       u64 nB, u32* __restrict__ tile_bytes,
                                                       u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ u64 tokc[TILE_BLOCKS];
     __shared__ u32 red[NT / 64];
+    __shared__ RsShared rs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
-    const u64 b = t * (u64)TILE_BLOCKS + tid;
-    stage_tile(bytes, N, tS, sh.bytes);
-    stage_tables(uni);
-    const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    {
+        TileRegs regs;
+        RsFetch rf;
+        tile_load(bytes, N, tS, regs);
+        rs_fetch(offsets, rec_lo, R, t, rf);
+        stage_tables(uni);
+        tile_store(regs, sh.bytes);
+        rs_store(rf, offsets, rec_lo, R, N, t, rs);
+    }
     __syncthreads();
-    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs_here, rs_next);
+    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs.w[tid], rs.w[tid + 1]);
     Plan pl = plan_passthrough(L.c, L.d.V);
     tokc[tid] = pl.TOK;
     __syncthreads();
@@ -1086,8 +1155,8 @@ __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* 
 // wavefront per listed line.  Lines of up to G3_MAXW blocks are re-classified from global memory by
 // five lanes and go through the same wave solver; the rest is walked serially by lane 0.
 constexpr u32 G3_VIEW = G3_MAXW + 1;
-__global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
-                                                     const u64* __restrict__ offsets, u64 R, u64 N, u64 nB, DevCfg cfg,
+__global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes,
+                                                     const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
                                                      Plan* plan, const u64* __restrict__ list,
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
                                                      u32* tile_toks, u64* __restrict__ totals) {
@@ -1114,8 +1183,8 @@ __global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes
                 const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
                 c = classify_block_fast(blk, nvalid, dev_tables());
                 const u64 V = below(nvalid);
-                const u64 RS = rsmap[wb] & V;
-                const bool nrs = (wb + 1 < nB) && (rsmap[wb + 1] & 1ull);
+                bool nrs;
+                const u64 RS = block_record_starts(offsets, rec_lo, R, N, wb, &nrs) & V;
                 const bool has_next = q + 64 < N;
                 const bool next_nl = has_next && blk[64] == '\n' && !nrs;
                 const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
@@ -1275,6 +1344,7 @@ struct EmitShared {
     EmitScan total;
     u64 cin_start;      // corpus position where the token that runs into this tile starts
     u32 flags;          // bit0: the tile's first byte continues a token that started before the tile
+    RsShared rs;
 };
 
 // Position where the token covering byte tS-1 starts (the tile's first byte continues it).
@@ -1314,26 +1384,27 @@ __device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 
 struct EmitIn {
     TileRegs regs;
     Plan pl;
-    u64 rs, rs_next;      // record-start words of the lane's block and of the next block
-    u64 prev_w, prev_rs;  // lane 0: token bytes / record starts of the block before the tile
+    RsFetch rf;           // record starts inside the tile
+    u64 prev_w;           // lane 0: token bytes of the block before the tile
+    u32 prev_rec;         // lane 0: start of the last record before the tile
     u64 next_w;           // last lane: token bytes of the block after the tile
     u64 base;             // scanned output byte / token base of the tile
 };
 template <bool PASSTHROUGH>
-__device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
-                                  const Plan* __restrict__ plan, const u64* __restrict__ tile_base, u64 N, u64 nB,
+__device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                  const u32* __restrict__ rec_lo, u64 R, const Plan* __restrict__ plan, const u64* __restrict__ tile_base, u64 N, u64 nB,
                                   u64 t, EmitIn& in) {
     const int tid = threadIdx.x;
     const u64 b = t * (u64)TILE_BLOCKS + tid;
     tile_load(bytes, N, t * (u64)TILE, in.regs);
-    in.rs = b < nB ? rsmap[b] : 0;
-    in.rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
+    const u32 r0 = rs_fetch(offsets, rec_lo, R, t, in.rf);
     Plan z = {0, 0, 0, 0};
     in.pl = z;
     if (!PASSTHROUGH && b < nB) in.pl = plan[b];
-    in.prev_w = in.prev_rs = in.next_w = 0;
+    in.prev_w = in.next_w = 0;
+    in.prev_rec = 0;
     if (tid == 0 && b > 0) {
-        in.prev_rs = rsmap[b - 1];
+        if (r0 > 0) in.prev_rec = (u32)offsets[r0 - 1];
         if (!PASSTHROUGH) in.prev_w = plan[b - 1].TOK & plan[b - 1].C;
     }
     if (!PASSTHROUGH && tid == NT - 1 && b + 1 < nB) in.next_w = plan[b + 1].TOK & plan[b + 1].C;
@@ -1342,7 +1413,7 @@ __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __res
 
 constexpr int EMIT_TPW = 4;   // consecutive tiles per workgroup
 template <bool PASSTHROUGH>
-__global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const u64* __restrict__ rsmap,
+__global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
                                               u64 N, u64 nB, u64 nT, const Plan* __restrict__ plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
@@ -1352,7 +1423,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     const int tid = threadIdx.x;
     const u64 t0 = (u64)blockIdx.x * EMIT_TPW;
     EmitIn in;
-    emit_fetch<PASSTHROUGH>(bytes, rsmap, plan, tile_base, N, nB, t0, in);
+    emit_fetch<PASSTHROUGH>(bytes, offsets, rec_lo, R, plan, tile_base, N, nB, t0, in);
 #pragma unroll 1
     for (int ti = 0; ti < EMIT_TPW; ti++) {
     const u64 t = t0 + ti;
@@ -1360,19 +1431,20 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
     const u64 tS = t * (u64)TILE;
     const u64 b = t * (u64)TILE_BLOCKS + tid;
     tile_store(in.regs, sh.tile.bytes);
+    rs_store(in.rf, offsets, rec_lo, R, N, t, sh.rs);
     const PadBlk blk = lane_block(sh.tile, tid);
     const u64 p = tS + (u64)tid * BLOCK;
     const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)BLOCK ? (N - p) : (u64)BLOCK);
     const u64 V = below(nvalid);
-    const u64 RS = in.rs & V;
-    const bool next_rs = !(p + BLOCK < N) || (in.rs_next & 1ull);
     Plan pl = in.pl;
     if (nvalid == 0) { Plan z = {0, 0, 0, 0}; pl = z; }
-    const u64 prev_w = in.prev_w, prev_rs = in.prev_rs;
+    const u64 prev_w = in.prev_w, prev_rec = in.prev_rec;
     bool edge_prev = false, edge_next = (in.next_w & 1ull) != 0;
     const u64 tb64 = in.base;
     __syncthreads();
-    if (ti + 1 < EMIT_TPW && t + 1 < nT) emit_fetch<PASSTHROUGH>(bytes, rsmap, plan, tile_base, N, nB, t + 1, in);
+    const u64 RS = sh.rs.w[tid] & V;
+    const bool next_rs = !(p + BLOCK < N) || (sh.rs.w[tid + 1] & 1ull);
+    if (ti + 1 < EMIT_TPW && t + 1 < nT) emit_fetch<PASSTHROUGH>(bytes, offsets, rec_lo, R, plan, tile_base, N, nB, t + 1, in);
     // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every tile after that phase
     if (stop_after == 1) { __syncthreads(); continue; }
     if (PASSTHROUGH) {
@@ -1411,21 +1483,21 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes, const
         if ((TOKC & 1ull) && prev_tok && !(RS & 1ull)) {
             sh.flags = 1;
             long long at = -1;   // start position inside the previous block, if it can be told from there
+            // the last record that starts before the tile, as a position in the previous block (or -1)
+            const long long rp = (prev_rec + 64 >= tS && prev_rec < tS) ? (long long)(prev_rec + 64 - tS) : -1;
             if (PASSTHROUGH) {
                 for (int k = 1; k <= 12; k++) {
-                    if ((prev_rs >> (64 - k)) & 1ull) { at = 64 - k; break; }
+                    if (rp == 64 - k) { at = 64 - k; break; }
                     if (byte_is_ws(blk, -k - 1)) { at = 64 - k; break; }
                 }
             } else {
                 u64 zeros = ~prev_w;   // bit 63 of prev_w is set
-                long long z = zeros ? top(zeros) + 1 : -1, r = prev_rs ? top(prev_rs) : -1;
-                at = z > r ? z : r;
+                long long z = zeros ? top(zeros) + 1 : -1;
+                at = z > rp ? z : rp;
             }
             if (at >= 0) sh.cin_start = (b - 1) * 64 + (u64)at;
             else {
-                u32 r0 = rec_lo[t];   // first record starting at/after tS; the covering record is r0-1
-                u64 rec_start = r0 > 0 ? offsets[r0 - 1] : 0;
-                sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, rec_start);
+                sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, prev_rec);
             }
         }
     }
@@ -1750,7 +1822,7 @@ struct DevBuf {
 struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf rec_lo, rsmap, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
+    DevBuf rec_lo, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
@@ -1872,7 +1944,7 @@ void trp_destroy(trp_ctx* c) {
     if (c->aux) { trp_destroy(c->aux); c->aux = nullptr; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->rec_lo, &c->rsmap, &c->SA, &c->seedJ, &c->seedS, &c->plan,
+    DevBuf* bufs[] = {&c->rec_lo, &c->SA, &c->seedJ, &c->seedS, &c->plan,
                       &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
@@ -1937,7 +2009,6 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     u64 g3_cap = N / 256 + 4096;
     if (c->g3list.cap / sizeof(u64) > g3_cap) g3_cap = c->g3list.cap / sizeof(u64);
     if ((rc = c->rec_lo.ensure((nT + 2) * sizeof(u32)))) return rc;
-    if ((rc = c->rsmap.ensure((nB + 2) * sizeof(u64)))) return rc;
     if ((rc = c->tile_bytes.ensure((nT + 1) * sizeof(u32)))) return rc;
     if ((rc = c->tile_toks.ensure((nT + 1) * sizeof(u32)))) return rc;
     if ((rc = c->tile_flags.ensure((nT + 1) * sizeof(u32)))) return rc;
@@ -1972,17 +2043,14 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     c->events.clear();
     HIPCHK(hipMemsetAsync(totals, 0, 8 * sizeof(u64), st));
 
-    u64* rsmap = c->rsmap.as<u64>();
     {
-        Prof pr(c, "k_rec_lo+rsmap");
+        Prof pr(c, "k_rec_lo");
         hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + 2 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, rec_lo);
-        HIPCHK(hipMemsetAsync(rsmap, 0, (nB + 2) * sizeof(u64), st));
-        if (R) hipLaunchKernelGGL(k_rsmap, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, rsmap);
     }
     if (nT) {
         if (!pass) {
             { Prof pr(c, "k_summary");
-              hipLaunchKernelGGL(k_summary, dim3((unsigned)((nT + SUM_TPW - 1) / SUM_TPW)), dim3(NT), 0, st, d_bytes, rsmap, N, nB,
+              hipLaunchKernelGGL(k_summary, dim3((unsigned)((nT + SUM_TPW - 1) / SUM_TPW)), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
                                  nT, dc.normalize, SA); }
             { Prof pr(c, "k_tile_carry");
               u32* far_count = reinterpret_cast<u32*>(totals + 7);   // zeroed with the totals
@@ -1991,15 +2059,15 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
               hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 4096)), dim3(NT), 0, st,
                                  SA, nT, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count); }
             { Prof pr(c, "k_plan");
-              hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, c->seedJ.as<J>(),
+              hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, c->seedJ.as<J>(),
                                  c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes, ttoks, tflags,
                                  c->plan_stop()); }
             { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(NT), 0, st, d_bytes, rsmap, d_offsets, R, N, nB, dc, plan,
+              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
                                  c->g3list.as<u64>(), totals + 6, g3_cap, tbytes, ttoks, totals); }
         } else {
             Prof pr(c, "k_count_tokens");
-            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, rsmap, N, nB, tbytes, ttoks,
+            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, tbytes, ttoks,
                                tflags);
         }
         { Prof pr(c, "scan_tiles");
@@ -2008,11 +2076,11 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
           if ((rc = scan_u64(c, c->packed.as<u64>(), nT, tile_base))) return rc; }
         { Prof pr(c, "k_emit");
           if (pass)
-              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes, rsmap,
+              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
                                  d_offsets, rec_lo, R, N, nB, nT, (const Plan*)nullptr, tile_base, (u8*)nullptr, c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off, c->emit_stop());
           else
-              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes, rsmap,
+              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
                                  d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off, c->emit_stop()); }
     }

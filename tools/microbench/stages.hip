@@ -11,7 +11,7 @@ __global__ __launch_bounds__(NT) void k_exp(const u8* __restrict__ bytes, const 
     __shared__ J wsum[NT / 64];
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
     const u64 b = t * (u64)TILE_BLOCKS + threadIdx.x;
-    stage_tile(bytes, N, tS, sh.bytes);
+    { TileRegs regs; tile_load(bytes, N, tS, regs); tile_store(regs, sh.bytes); }
     stage_tables(uni);
     const u64 rs_here = b < nB ? rsmap[b] : 0, rs_next = b + 1 < nB ? rsmap[b + 1] : 0;
     __syncthreads();
