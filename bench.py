@@ -9,6 +9,10 @@ batch that is already resident in HBM.  Workload at every N: BASELINE.json confi
 synthetic ASCII English, records of 3072-5120 bytes, denoiser enabled, default chunking - per GPU
 (weak scaling: records shard by range, no inter-GPU traffic in the timed region).  Rank 0 prints one
 JSON line.
+
+--config E is BASELINE.json configs[4]: a 64e9-byte corpus (OCR-noisy markdown generator) cut by record
+range into one shard per GPU (strong scaling); a shard is held in HBM as slices of at most 4e9 bytes,
+each one batch, and a step is one pass over all slices of the shard.
 """
 import argparse
 import ctypes as C
@@ -48,8 +52,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bytes", type=int, default=1_000_000_000, help="bytes per GPU")
-    ap.add_argument("--config", default="B", choices=["B", "C", "D"])
+    ap.add_argument("--bytes", type=int, default=None,
+                    help="bytes per GPU (default 1e9); with --config E the bytes of the whole corpus (default 64e9)")
+    ap.add_argument("--config", default="B", choices=["B", "C", "D", "E"])
     ap.add_argument("--no-denoise", action="store_true")
     ap.add_argument("--normalize", action="store_true",
                     help="time normalize_inline_whitespace (the step before the path) instead of the path")
@@ -81,33 +86,63 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # ---- synthetic batch for this rank (shard = its own record range of the corpus) -----------------
+    # ---- synthetic batches for this rank (shard = its own record range of the corpus) ---------------
     threads = max(1, 16 // max(1, world))
-    seed = {"B": 42, "C": 43, "D": 44}[args.config] + 1000 * rank
     t0 = time.time()
-    if args.config == "B":
-        data, offs = corpusgen.config_b(args.bytes, seed, threads)
-        workload = "config B: %.1e B synthetic ASCII English, records 3072-5120 B" % args.bytes
-    elif args.config == "C":
-        data, offs = corpusgen.config_c(args.bytes, seed, threads)
-        workload = "config C: %.1e B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB" % args.bytes
+    batches = []      # (device bytes, device offsets, R, N), all resident in HBM before the timed region
+    host0 = None      # host copy of the first batch (CPU baseline, host path)
+    if args.config == "E":
+        total = args.bytes or 64_000_000_000
+        lo, hi = total * rank // world, total * (rank + 1) // world     # this rank's byte range of the corpus
+        n_slices = max(1, -(-(hi - lo) // 4_000_000_000))
+        for i in range(n_slices):
+            a, b = lo + (hi - lo) * i // n_slices, lo + (hi - lo) * (i + 1) // n_slices
+            data, offs = corpusgen.config_c(b - a, 45 + 1000 * rank + i, threads)
+            batches.append((torch.from_numpy(data).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda(),
+                            int(len(offs) - 1), int(len(data))))
+            if host0 is None:
+                host0 = (data, offs)
+            del data, offs
+        workload = ("config E: %.1e B synthetic OCR-noisy markdown corpus, one record-range shard per GPU, "
+                    "%d slice(s) of <= 4e9 B per shard" % (total, n_slices))
     else:
-        data, offs = corpusgen.config_d(args.bytes, seed, threads)
-        workload = "config D: %.1e B skewed lengths, half the bytes in 200 B and half in 1 MiB records" % args.bytes
+        nbytes = args.bytes or 1_000_000_000
+        seed = {"B": 42, "C": 43, "D": 44}[args.config] + 1000 * rank
+        if args.config == "B":
+            data, offs = corpusgen.config_b(nbytes, seed, threads)
+            workload = "config B: %.1e B synthetic ASCII English, records 3072-5120 B" % nbytes
+        elif args.config == "C":
+            data, offs = corpusgen.config_c(nbytes, seed, threads)
+            workload = "config C: %.1e B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB" % nbytes
+        else:
+            data, offs = corpusgen.config_d(nbytes, seed, threads)
+            workload = "config D: %.1e B skewed lengths, half the bytes in 200 B and half in 1 MiB records" % nbytes
+        batches.append((torch.from_numpy(data).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda(),
+                        int(len(offs) - 1), int(len(data))))
+        host0 = (data, offs)
     gen_s = time.time() - t0
-    N, R = int(len(data)), int(len(offs) - 1)
-    d_bytes = torch.from_numpy(data).cuda()
-    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    data, offs = host0
+    N = sum(b[3] for b in batches)
+    R = sum(b[2] for b in batches)
+    nb = len(batches)
     torch.cuda.synchronize()
 
     den = T.DenoiserConfig(enabled=not args.no_denoise, max_digit_ratio=0.35, strip_markdown=True)
     st = T.ChunkingStrategy()   # reference defaults: 1024 / [64] / 512
     ctx = T.Context(device)
 
-    def step():
-        if args.normalize:
-            return ctx.normalize_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N)
-        return ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
+    def step(after_batch=None):
+        """One pass over the rank's shard; returns (denoised bytes, tokens, chunks)."""
+        d = t = c = 0
+        for d_bytes, d_offs, r, n in batches:
+            if args.normalize:
+                res = ctx.normalize_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n)
+            else:
+                res = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
+            d, t, c = d + int(res.n_denoised), t + int(res.n_tokens), c + int(res.n_chunks)
+            if after_batch is not None:
+                after_batch()
+        return d, t, c
 
     for _ in range(args.warmup):
         res = step()
@@ -133,8 +168,8 @@ def main():
     else:
         total_bytes = float(N)
 
-    stats = {"N": N, "R": R, "D": int(res.n_denoised), "T": int(res.n_tokens), "C": int(res.n_chunks),
-             "enabled": den.enabled}
+    stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled}
+    per_launch = {k: (v // nb if k != "enabled" else v) for k, v in stats.items()}   # average batch of the shard
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes * args.steps / elapsed / 1e9
 
@@ -142,14 +177,17 @@ def main():
     ctx.set_profiling(True)
     acc = {}
     reps = max(3, min(args.steps, 10))
-    for _ in range(reps):
-        step()
+
+    def collect():
         for name, ms in ctx.profile():
             acc[name] = acc.get(name, 0.0) + ms
+
+    for _ in range(reps):
+        step(collect)
     ctx.set_profiling(False)
-    kern = {k: v / reps for k, v in acc.items()}
+    kern = {k: v / (reps * nb) for k, v in acc.items()}   # per launch
     dominant = max(kern, key=kern.get)
-    dom_bytes = KERNEL_BYTES.get(dominant, lambda s: s["N"])(stats)
+    dom_bytes = KERNEL_BYTES.get(dominant, lambda s: s["N"])(per_launch)
     achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -165,7 +203,7 @@ def main():
             with open(tr) as f:
                 tj = json.load(f)
             meta = tj.get("_meta", {})
-            same = (meta.get("bytes_per_gpu") == N and meta.get("workload") == workload
+            same = (nb == 1 and meta.get("bytes_per_gpu") == N and meta.get("workload") == workload
                     and meta.get("denoiser") == ("enabled" if den.enabled else "disabled") and not args.normalize)
             if same:
                 roofline["traffic"] = (tj.get(dominant) or {}).get("bytes")
@@ -176,8 +214,8 @@ def main():
         "metric": "device-resident GB/s of text denoised+tokenised+chunked",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R,
+        "scaling": "strong" if args.config == "E" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R, "batches_per_step": nb,
                    "denoiser": "normalize_inline_whitespace" if args.normalize else ("enabled" if den.enabled else "disabled"),
                    "chunking": "max_window_tokens=1024 overlap=[64] summary_fallback_tokens=512",
                    "sharding": "record ranges, one shard per GPU, no collective"},
@@ -188,6 +226,7 @@ def main():
 
     # ---- the same batch handed over in host memory: H2D of the input and D2H of every result array -----
     if args.host_path and rank == 0:
+        N, R = batches[0][3], batches[0][2]     # the first batch of the shard
         pinned = torch.from_numpy(data).pin_memory()
         offs64 = np.ascontiguousarray(offs, dtype=np.uint64)
         L = T.load_library()
@@ -208,6 +247,10 @@ def main():
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.normalize:
         import oracle_lib as O
+        N, R = batches[0][3], batches[0][2]     # the first batch of the shard
+        if nb > 1:
+            first = ctx.preprocess_batch_device(batches[0][0].data_ptr(), batches[0][1].data_ptr(), R, N, den, st)
+            stats = {"D": int(first.n_denoised), "T": int(first.n_tokens), "C": int(first.n_chunks)}
         cfg = O.make_config(den.enabled, 0.35, True, 1024, (64,), 512)
         cut = int(np.searchsorted(offs, min(N, 256_000_000), side="right")) - 1
         cut = max(cut, 1)
