@@ -769,45 +769,11 @@ __device__ inline bool g3_wave_solve(const G3Masks& a, u32 s, bool table, bool r
     return true;
 }
 
-// The same solver run by a single lane (one line per lane, 64 lines per wave at a time): two serial
-// walks over the line's tokens on the block masks, with the expansion in between done as mask algebra
-// in token space (bit t = token t).  Used inside k_plan where a tile holds dozens of short digit-heavy
-// lines.  Returns false when the line does not fit (more than G3_MAXW blocks or 64 tokens).
-struct G3Walk {
-    const G3Masks& a;
-    u32 w0, w1, s, e;
-    bool table;
-    __device__ u64 range(u32 w) const {
-        u64 r = ~0ull;
-        if (w == w0) r &= ~below((int)(s & 63u));
-        if (w == w1 && (e & 63u)) r &= below((int)(e & 63u));
-        return r;
-    }
-    __device__ u64 runs(u32 w) const { return ~(a.ws[w] | (table ? a.pipe[w] : 0ull)) & range(w); }
-    // Calls f(w, mask, first_part, last_part) for every piece of every token, in order: a token is one
-    // piece unless it crosses a block edge.
-    template <class F>
-    __device__ void for_each_piece(F f) const {
-        bool open = false;
-        for (u32 w = w0; w <= w1; w++) {
-            u64 x = runs(w);
-            if (open && !(x & 1ull)) { f(w, 0ull, false, true); open = false; }   // ended at the block edge
-            while (x) {
-                const int p = ctz(x);
-                const u64 r = ~x >> p;
-                const int len = r ? ctz(r) : 64 - p;
-                const u64 m = (len == 64 ? ~0ull : (below(len) << p));
-                const bool reaches_edge = p + len == 64 && w < w1;
-                f(w, m, !open, !reaches_edge);
-                open = reaches_edge;
-                x &= ~m;
-                if (reaches_edge) break;
-            }
-        }
-        if (open) f(w1, 0ull, false, true);
-    }
-};
-
+// The same problem solved by a single lane (one line per lane, 64 lines per wave at a time) with
+// g3_bits_solve: no walk over the tokens, no limit on their number.  Used inside k_plan where a tile
+// holds dozens of short digit-heavy lines.  Returns false when the line does not fit (more than
+// G3_WORDS blocks).
+static_assert(G3_WORDS == (int)G3_MAXW, "the lane solver and the wave solver take the same lines");
 __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
                                      float max_ratio) {
     const u32 w0 = s >> 6;
@@ -823,68 +789,39 @@ __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool r
     }
     const u32 w1 = (e - 1u) >> 6;
     if (w1 - w0 >= G3_MAXW) return false;
-    const G3Walk walk = {a, w0, w1, s, e, table};
-    // walk 1: per-token digit counts as bit planes over token numbers, tokens with a letter, letters in all
-    u64 A = 0, pd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u32 nt = 0, dig = 0, alp = 0, a0 = 0;
-    walk.for_each_piece([&](u32 w, u64 m, bool first_part, bool last_part) {
-        if (first_part) { dig = 0; alp = 0; }
-        dig += (u32)popc(a.dig[w] & m);
-        alp += (u32)popc(a.alp[w] & m);
-        if (last_part) {
-            if (nt < 64) {
-                if (alp) A |= 1ull << nt;
+    G3Bits X, DG, AL;
 #pragma unroll
-                for (int k = 0; k < 8; k++) pd[k] |= (u64)((dig >> k) & 1u) << nt;
-            }
-            a0 += alp;
-            nt++;
+    for (u32 j = 0; j < G3_MAXW; j++) {
+        X.w[j] = DG.w[j] = AL.w[j] = 0;
+        const u32 w = w0 + j;
+        if (w <= w1) {
+            u64 range = ~0ull;
+            if (j == 0) range &= ~below((int)(s & 63u));
+            if (w == w1 && (e & 63u)) range &= below((int)(e & 63u));
+            X.w[j] = ~(a.ws[w] | (table ? a.pipe[w] : 0ull)) & range;
+            DG.w[j] = a.dig[w] & range;
+            AL.w[j] = a.alp[w] & range;
         }
-    });
-    if (nt == 0 || nt > 64) return false;
-    // expansion (denoiser_preprocessor.rs:94-131)
-    const u64 valid = below((int)nt);
-    u64 d0 = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) d0 += (u64)popc(pd[k] & A) << k;
-    u64 kept = A;
-    while (true) {
-        const u64 next = (kept | (kept << 1) | (kept >> 1)) & valid;
-        const u64 wave_k = next & ~kept;
-        if (!wave_k) break;
-        u64 wd = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) wd += (u64)popc(pd[k] & wave_k) << k;
-        if (ratio_exceeds64(d0 + wd, (u64)a0, max_ratio)) break;
-        d0 += wd;
-        kept = next;
     }
-    // walk 2: the bytes of the kept tokens, a separator flag at the start of each
-    u32 t = 0;
-    bool first_kept = true, keep = false;
-    u64 g = 0, psp = 0, pnl = 0;
-    u32 cur_w = w0;
-    auto flush = [&](u32 w) {
-        if (g) atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w]), g);
-        if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[w]), psp);
-        if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[w]), pnl);
-        g = psp = pnl = 0;
-    };
-    walk.for_each_piece([&](u32 w, u64 m, bool first_part, bool last_part) {
-        if (w != cur_w) { flush(cur_w); cur_w = w; }
-        if (first_part) {
-            keep = (kept >> t) & 1ull;
-            if (keep) {
-                const u64 low = m & (0ull - m);
-                if (!first_kept) psp |= low;
-                else if (rab) pnl |= low;
-                first_kept = false;
+    const G3Bits K = g3_bits_solve(X, DG, AL, max_ratio);
+    const G3Bits KS = g3b_run_starts(K);   // kept tokens are whole tokens: their starts are the runs' starts of K & X
+    bool first = true;
+#pragma unroll
+    for (u32 j = 0; j < G3_MAXW; j++) {
+        const u64 g = K.w[j];
+        if (g) {
+            u64 psp = KS.w[j], pnl = 0;
+            if (first && psp) {
+                const u64 low = psp & (0ull - psp);
+                psp &= ~low;
+                if (rab) pnl = low;
+                first = false;
             }
+            atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w0 + j]), g);
+            if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[w0 + j]), psp);
+            if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[w0 + j]), pnl);
         }
-        if (keep) g |= m;
-        if (last_part) t++;
-    });
-    flush(cur_w);
+    }
     return true;
 }
 

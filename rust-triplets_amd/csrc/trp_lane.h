@@ -911,4 +911,150 @@ TRP_HD u64 g3_solve_K(ByteSrc& s, u64 p, u64 e, bool table, float max_ratio, con
     }
 }
 
+// ---- gate 3 on bit masks -----------------------------------------------------------------------------
+// A line of at most G3_WORDS blocks solved without walking its tokens: every set of tokens is the mask of
+// its bytes (bit i = byte i of the first block of the line, G3_WORDS x 64 bits), and "the token after /
+// before a kept token" is found with carry chains.  Adding a point to a mask of runs of ones clears the
+// run from the point upwards and sets the first zero above it; the mirror image (bits reversed) does the
+// same downwards.
+constexpr int G3_WORDS = 4;
+struct G3Bits {
+    u64 w[G3_WORDS];
+};
+TRP_HD u64 bitrev64(u64 x) {
+#if defined(__clang__)
+    return __builtin_bitreverse64(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+TRP_HD G3Bits g3b_rev(const G3Bits& a) {
+    G3Bits r;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) r.w[j] = bitrev64(a.w[G3_WORDS - 1 - j]);
+    return r;
+}
+TRP_HD G3Bits g3b_add(const G3Bits& a, const G3Bits& b) {
+    G3Bits r;
+#if defined(__clang__)
+    unsigned long long c = 0;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) r.w[j] = __builtin_addcll(a.w[j], b.w[j], c, &c);
+#else
+    u64 c = 0;
+    for (int j = 0; j < G3_WORDS; j++) {
+        const u64 s1 = a.w[j] + b.w[j], s2 = s1 + c;
+        c = (u64)(s1 < a.w[j]) | (u64)(s2 < s1);
+        r.w[j] = s2;
+    }
+#endif
+    return r;
+}
+TRP_HD G3Bits g3b_and(const G3Bits& a, const G3Bits& b) {
+    G3Bits r;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] & b.w[j];
+    return r;
+}
+TRP_HD G3Bits g3b_andn(const G3Bits& a, const G3Bits& b) {   // a & ~b
+    G3Bits r;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] & ~b.w[j];
+    return r;
+}
+TRP_HD G3Bits g3b_or(const G3Bits& a, const G3Bits& b) {
+    G3Bits r;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] | b.w[j];
+    return r;
+}
+TRP_HD G3Bits g3b_orn(const G3Bits& a, const G3Bits& b) {   // a | ~b
+    G3Bits r;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] | ~b.w[j];
+    return r;
+}
+TRP_HD bool g3b_any(const G3Bits& a) {
+    u64 x = 0;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) x |= a.w[j];
+    return x != 0;
+}
+TRP_HD u32 g3b_popc_and(const G3Bits& a, const G3Bits& b) {
+    u32 n = 0;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) n += (u32)popc(a.w[j] & b.w[j]);
+    return n;
+}
+// first bytes / last bytes of the runs of ones
+TRP_HD G3Bits g3b_run_starts(const G3Bits& x) {
+    G3Bits r;
+    u64 c = 0;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) {
+        r.w[j] = x.w[j] & ~((x.w[j] << 1) | c);
+        c = x.w[j] >> 63;
+    }
+    return r;
+}
+TRP_HD G3Bits g3b_run_ends(const G3Bits& x) {
+    G3Bits r;
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) {
+        const u64 nx = j + 1 < G3_WORDS ? x.w[j + 1] << 63 : 0ull;
+        r.w[j] = x.w[j] & ~((x.w[j] >> 1) | nx);
+    }
+    return r;
+}
+// the bytes from each point (at most one per run, inside a run of x) to the end of its run
+TRP_HD G3Bits g3b_run_from(const G3Bits& x, const G3Bits& points) { return g3b_andn(x, g3b_add(x, points)); }
+
+// The bytes of the tokens that strip_digit_tokens keeps (denoiser_preprocessor.rs:70-140).  X: bytes of
+// the line's tokens; DG / AL: its ASCII digits / alphabetic characters (one bit per character).
+// Keeps the compiler from carrying loop-invariant derived masks (mirror images, run starts) in registers
+// across the expansion loop: they are cheap to recompute and the kernel's occupancy depends on it.
+TRP_HD void g3b_opaque(G3Bits& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    TRP_UNROLL
+    for (int j = 0; j < G3_WORDS; j++) asm volatile("" : "+v"(x.w[j]));
+#else
+    (void)x;
+#endif
+}
+TRP_HD G3Bits g3_bits_solve(G3Bits X, const G3Bits& DG, const G3Bits& AL, float max_ratio) {
+    // seed: the tokens with a letter.  P = the first letter of each such token (the carry from the token
+    // start runs through the letterless bytes Y and stops on a letter or on the separator after the token)
+    G3Bits K;
+    {
+        const G3Bits Y = g3b_andn(X, AL);
+        const G3Bits P = g3b_and(g3b_andn(g3b_add(Y, g3b_run_starts(X)), Y), AL);
+        K = g3b_or(g3b_run_from(X, P), g3b_rev(g3b_run_from(g3b_rev(X), g3b_rev(P))));
+    }
+    const u32 a0 = g3b_popc_and(AL, X);
+    u32 d0 = g3b_popc_and(DG, K);
+    for (;;) {
+        g3b_opaque(X);
+        // Z: kept bytes and everything that is not a token; a carry from a kept token's first (last) byte
+        // stops on the first (last) byte of the next (previous) token that is not kept.  The kept tokens
+        // are the runs of K.
+        const G3Bits Z = g3b_orn(K, X);
+        const G3Bits NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
+        G3Bits W = g3b_run_from(X, NS);
+        {
+            const G3Bits rZ = g3b_rev(Z);
+            const G3Bits rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
+            W = g3b_or(W, g3b_rev(g3b_run_from(g3b_rev(X), rPE)));
+        }
+        if (!g3b_any(W)) break;
+        const u32 wd = g3b_popc_and(DG, W);
+        if (ratio_exceeds(d0 + wd, a0, max_ratio)) break;
+        d0 += wd;
+        K = g3b_or(K, W);
+    }
+    return K;
+}
+
 }  // namespace trp

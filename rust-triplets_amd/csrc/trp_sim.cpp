@@ -209,9 +209,33 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                 u64 rec_end = offsets[lo + 1];
                 u64 e = p;
                 while (e < rec_end && base[e] != '\n' && base[e] != '\r') e++;
-                u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
                 pb.clear_marker(p);
                 bool first = true;
+                const u64 w0 = p >> 6, w1 = e > p ? (e - 1) >> 6 : w0;
+                if (w1 - w0 < (u64)G3_WORDS) {   // short line: the bit-mask solver, as in k_plan
+                    G3Bits X, DG, AL;
+                    for (int jw = 0; jw < G3_WORDS; jw++) {
+                        X.w[jw] = DG.w[jw] = AL.w[jw] = 0;
+                        const u64 w = w0 + jw;
+                        if (w > w1) continue;
+                        u64 range = ~0ull;
+                        if (w == w0) range &= ~below((int)(p & 63));
+                        if (w == w1 && (e & 63)) range &= below((int)(e & 63));
+                        X.w[jw] = ~(cls[w].ws | (table ? cls[w].pipe : 0ull)) & range;
+                        DG.w[jw] = cls[w].dig & range;
+                        AL.w[jw] = cls[w].alp & range;
+                    }
+                    const G3Bits Kb = g3_bits_solve(X, DG, AL, cfg.max_digit_ratio);
+                    for (u64 q = p; q < e; q++) {
+                        const u64 i = q - w0 * 64;
+                        if (!((Kb.w[i >> 6] >> (i & 63)) & 1)) continue;
+                        const bool start = i == 0 || !((Kb.w[(i - 1) >> 6] >> ((i - 1) & 63)) & 1);
+                        pb.set(q, true, true, start ? (first ? (rab ? 2 : 0) : 1) : 0);
+                        if (start) first = false;
+                    }
+                    continue;
+                }
+                u64 K = g3_solve_K(src, p, e, table, cfg.max_digit_ratio, ut);
                 g3_walk(src, p, e, table, ut,
                         [&](const TokInfo& t, u64 dist) {
                             if (dist > K) return;
