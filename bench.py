@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--normalize", action="store_true",
                     help="time normalize_inline_whitespace (the step before the path) instead of the path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocking", action="store_true",
+                    help="time blocking calls on one context instead of batches in flight on two")
     ap.add_argument("--host-path", action="store_true",
                     help="also time trp_preprocess_batch on host buffers (PCIe both ways included)")
     args = ap.parse_args()
@@ -144,15 +146,48 @@ def main():
                 after_batch()
         return d, t, c
 
-    for _ in range(args.warmup):
-        res = step()
+    # Timed region: batches are kept in flight on two contexts (two sets of result buffers, one stream
+    # each) the way a consumer of one batch overlaps with the production of the next; every batch of every
+    # step is waited for inside the region.  --blocking times back-to-back blocking calls on one context.
+    ctx2 = None if (args.blocking or args.normalize) else T.Context(device)
+
+    def run_steps(k):
+        """k passes over the shard; returns the (denoised bytes, tokens, chunks) of the last pass."""
+        if ctx2 is None:
+            for _ in range(k):
+                r = step()
+            return r
+        cs, busy, tot = (ctx, ctx2), [False, False], [0, 0, 0]
+        i = 0
+
+        def reap(j, last):
+            r = cs[j].wait_batch()
+            busy[j] = False
+            if last:
+                tot[0] += int(r.n_denoised); tot[1] += int(r.n_tokens); tot[2] += int(r.n_chunks)
+
+        pend = [False, False]   # whether the batch in flight on context j belongs to the last pass
+        for s in range(k):
+            for d_bytes, d_offs, r, n in batches:
+                j = i % 2
+                if busy[j]:
+                    reap(j, pend[j])
+                cs[j].submit_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
+                busy[j], pend[j] = True, s == k - 1
+                i += 1
+        for j in (i % 2, (i + 1) % 2):
+            if busy[j]:
+                reap(j, pend[j])
+        return tuple(tot)
+
+    if args.warmup:
+        run_steps(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()                     # returns after the context's stream has drained
+    res = run_steps(args.steps)          # returns after every batch of every step has completed
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -218,7 +253,9 @@ def main():
         "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R, "batches_per_step": nb,
                    "denoiser": "normalize_inline_whitespace" if args.normalize else ("enabled" if den.enabled else "disabled"),
                    "chunking": "max_window_tokens=1024 overlap=[64] summary_fallback_tokens=512",
-                   "sharding": "record ranges, one shard per GPU, no collective"},
+                   "sharding": "record ranges, one shard per GPU, no collective",
+                   "calls": "blocking, one context" if ctx2 is None else
+                            "submit/wait, one batch in flight on each of two contexts"},
         "outputs": {"denoised_bytes": stats["D"], "tokens": stats["T"], "chunks": stats["C"]},
         "roofline": roofline,
         "corpus_generation_s": round(gen_s, 2),
@@ -277,6 +314,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
+    if ctx2 is not None:
+        ctx2.close()
     if dist is not None:
         dist.destroy_process_group()
 

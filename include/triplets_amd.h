@@ -127,6 +127,16 @@ int trp_preprocess_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint
                                 uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
                                 trp_result* out);
 
+/* The same call in two halves, for callers that keep several batches in flight the way the reference's
+ * BatchPrefetcher produces batches ahead of their consumer (src/sampler/mod.rs:159-248):
+ * trp_submit_batch_device enqueues the whole path on the context's stream and returns at once;
+ * trp_wait_batch waits for it and fills `out` exactly as trp_preprocess_batch_device does.  One batch
+ * per context may be in flight; contexts run concurrently with each other (one stream each).  The input
+ * buffers must stay untouched until trp_wait_batch returns. */
+int trp_submit_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                            uint64_t n_records, uint64_t n_bytes, const trp_config* cfg);
+int trp_wait_batch(trp_ctx* ctx, trp_result* out);
+
 /* Copy `bytes` bytes of a device array of the last result into host memory (ordered on the context's
  * stream, returns when the copy is complete). */
 int trp_copy_to_host(trp_ctx* ctx, void* dst, const void* d_src, size_t bytes);

@@ -1774,6 +1774,14 @@ struct trp_ctx {
     u64 last_R = 0;
     bool have_last = false;
     trp_ctx* aux = nullptr;             // second set of buffers + stream for the pipelined host path
+    // batch in flight between submit_device and collect_device
+    struct Pending {
+        bool active = false;
+        const uint8_t* d_bytes = nullptr;
+        const uint64_t* d_offsets = nullptr;
+        u64 R = 0, N = 0, nT = 0, g3_cap = 0, chunk_cap = 0;
+        DevCfg dc = {};
+    } pending;
     // Profiling aid: with profiling on and TRP_PROFILE_EMIT_STOP=k (1..5) in the environment, k_emit ends
     // every tile after phase k, so that the phases can be timed one by one.  The results of such a call
     // are incomplete; calls without profiling are never affected.
@@ -1923,9 +1931,11 @@ __global__ void k_add_chunk_record(ChunkDesc* __restrict__ c, u64 n, u32 add) {
 }
 }  // namespace
 
-static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
-                      const DevCfg& dc, trp_result* out) {
-    if (!c || !out) return fail(TRP_E_ARG, "ctx/out is null");
+// Enqueues the whole path for one batch on the context's stream and returns without waiting.
+static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
+                         const DevCfg& dc) {
+    if (!c) return fail(TRP_E_ARG, "ctx is null");
+    if (c->pending.active) return fail(TRP_E_ARG, "a batch is already in flight on this context");
     if (!d_offsets) return fail(TRP_E_ARG, "offsets is null");
     if (N && !d_bytes) return fail(TRP_E_ARG, "bytes is null");
     if (((uintptr_t)d_bytes & 15u) != 0) return fail(TRP_E_ARG, "bytes must be 16-byte aligned");
@@ -2035,16 +2045,43 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
                          c->chunks.as<ChunkDesc>(), totals); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_totals, totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    c->pending.active = true;
+    c->pending.d_bytes = d_bytes;
+    c->pending.d_offsets = d_offsets;
+    c->pending.R = R;
+    c->pending.N = N;
+    c->pending.nT = nT;
+    c->pending.g3_cap = g3_cap;
+    c->pending.chunk_cap = chunk_cap;
+    c->pending.dc = dc;
+    return TRP_OK;
+}
+
+// Waits for the batch in flight, repeats what overflowed an optimistic buffer, and describes the result.
+static int collect_device(trp_ctx* c, trp_result* out) {
+    if (!c || !out) return fail(TRP_E_ARG, "ctx/out is null");
+    if (!c->pending.active) return fail(TRP_E_ARG, "no batch in flight on this context");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    const trp_ctx::Pending pd = c->pending;
+    c->pending.active = false;
+    hipStream_t st = c->stream;
+    const DevCfg& dc = pd.dc;
+    const bool pass = !dc.denoise_enabled;
+    const u64 R = pd.R, nT = pd.nT;
+    u64* totals = c->totals.as<u64>();
+    u64 *den_off = c->den_off.as<u64>(), *tok_off = c->tok_off.as<u64>(), *chunk_off = c->chunk_off.as<u64>();
     HIPCHK(hipStreamSynchronize(st));
     if (!pass && nT && c->h_totals[5]) {
         // more digit-heavy lines than the work list holds: grow it to the exact size and run the batch again
-        if (c->h_totals[4] <= g3_cap) return fail(TRP_E_HIP, "inconsistent gate-3 list size");
+        if (c->h_totals[4] <= pd.g3_cap) return fail(TRP_E_HIP, "inconsistent gate-3 list size");
         if ((rc = c->g3list.ensure(c->h_totals[4] * sizeof(u64)))) return rc;
-        return run_device(c, d_bytes, d_offsets, R, N, dc, out);
+        if ((rc = submit_device(c, pd.d_bytes, pd.d_offsets, pd.R, pd.N, dc))) return rc;
+        return collect_device(c, out);
     }
     if (c->h_totals[3]) {
         // the optimistic descriptor buffer was too small: grow to the exact size and emit again
-        chunk_cap = c->h_totals[2];
+        const u64 chunk_cap = c->h_totals[2];
         if ((rc = c->chunks.ensure(chunk_cap * sizeof(ChunkDesc)))) return rc;
         hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, chunk_cap,
                            c->chunks.as<ChunkDesc>(), totals);
@@ -2066,7 +2103,7 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
         c->events.clear();
     }
     memset(out, 0, sizeof(*out));
-    out->denoised = pass ? const_cast<uint8_t*>(d_bytes) : c->denoised.as<u8>();
+    out->denoised = pass ? const_cast<uint8_t*>(pd.d_bytes) : c->denoised.as<u8>();
     out->denoised_offsets = den_off;
     out->dropped = c->dropped.as<u8>();
     out->tok_start = c->tok_start.as<u32>();
@@ -2082,6 +2119,14 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     c->last_R = R;
     c->have_last = true;
     return TRP_OK;
+}
+
+static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
+                      const DevCfg& dc, trp_result* out) {
+    if (!c || !out) return fail(TRP_E_ARG, "ctx/out is null");
+    int rc = submit_device(c, d_bytes, d_offsets, R, N, dc);
+    if (rc) return rc;
+    return collect_device(c, out);
 }
 
 // Text of `C` descriptors over the last device batch: lengths, scan, emit.  chunk_off == nullptr for head
@@ -2152,6 +2197,16 @@ int trp_preprocess_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64
     if (rc) return rc;
     return run_device(c, d_bytes, d_offsets, R, N, dc, out);
 }
+
+int trp_submit_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
+                            const trp_config* cfg) {
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    return submit_device(c, d_bytes, d_offsets, R, N, dc);
+}
+
+int trp_wait_batch(trp_ctx* c, trp_result* out) { return collect_device(c, out); }
 
 int trp_normalize_batch_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R,
                                uint64_t N, trp_result* out) {

@@ -62,7 +62,8 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_result_free", "trp_preprocess_batch_device", "trp_copy_to_host",
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
-           "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device"]
+           "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
+           "trp_submit_batch_device", "trp_wait_batch"]
 
 _lib = None
 
@@ -93,6 +94,9 @@ def load_library():
     L.trp_result_free.argtypes = [C.POINTER(_Result)]
     L.trp_preprocess_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                               C.c_uint64, C.POINTER(_Config), C.POINTER(_Result)]
+    L.trp_submit_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                          C.POINTER(_Config)]
+    L.trp_wait_batch.argtypes = [C.c_void_p, C.POINTER(_Result)]
     L.trp_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.trp_materialize_chunk_text_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p),
                                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -374,6 +378,19 @@ class Context:
         res = _Result()
         _check(self._L.trp_preprocess_batch_device(self._h, d_bytes, d_offsets, n_records, n_bytes,
                                                    C.byref(cfg), C.byref(res)))
+        return DeviceResult(self, res)
+
+    def submit_batch_device(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int,
+                            denoiser: DenoiserConfig, strategy: ChunkingStrategy) -> None:
+        """Enqueue the path for a device-resident batch and return at once; wait_batch() gives the result.
+        One batch per context may be in flight."""
+        cfg = _make_cfg(denoiser, strategy)
+        self._cfg_in_flight = cfg   # the overlaps array must outlive the call
+        _check(self._L.trp_submit_batch_device(self._h, d_bytes, d_offsets, n_records, n_bytes, C.byref(cfg)))
+
+    def wait_batch(self) -> DeviceResult:
+        res = _Result()
+        _check(self._L.trp_wait_batch(self._h, C.byref(res)))
         return DeviceResult(self, res)
 
     def materialize_chunk_text(self):

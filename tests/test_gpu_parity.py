@@ -201,3 +201,39 @@ def test_chunk_text_materialisation(T, ctx):
         assert L.trp_copy_to_host(ctx._h, text.ctypes.data, tptr, text.nbytes) == 0
     for c in range(host.n_chunks):
         assert text[int(toff[c]):int(toff[c + 1])].tobytes() == exp.chunk_text(c), c
+
+
+def test_submit_and_wait_on_two_contexts(T, ctx):
+    """Two batches in flight on two contexts (the halves of the blocking call) give the blocking results."""
+    import torch
+    den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy(16, [3], 0.35, 4)
+    other = T.Context(0)
+    try:
+        with pytest.raises(T.TripletsAmdError):
+            ctx.wait_batch()                      # nothing in flight
+        batches = []
+        for seed in (21, 22, 23, 24):
+            recs = textgen.corpus(seed, 400) + [textgen.digit_heavy_long_line(__import__("random").Random(seed), 90)]
+            data, offs = O.pack(recs)
+            batches.append((recs, data, offs, torch.from_numpy(data).cuda(),
+                            torch.from_numpy(offs.astype(np.int64)).cuda()))
+        torch.cuda.synchronize()
+        cs = [ctx, other]
+        inflight = [None, None]
+        got = {}
+        for i, (recs, data, offs, db, do) in enumerate(batches):
+            k = i % 2
+            if inflight[k] is not None:
+                got[inflight[k]] = cs[k].wait_batch().to_host()
+            cs[k].submit_batch_device(db.data_ptr(), do.data_ptr(), len(recs), len(data), den, st)
+            inflight[k] = i
+            if i == 0:
+                with pytest.raises(T.TripletsAmdError):   # one batch per context
+                    cs[k].submit_batch_device(db.data_ptr(), do.data_ptr(), len(recs), len(data), den, st)
+        for k in (0, 1):
+            got[inflight[k]] = cs[k].wait_batch().to_host()
+        for i, (recs, data, offs, db, do) in enumerate(batches):
+            exp = O.batch(data, offs, O.make_config(True, 0.35, True, 16, (3,), 4))
+            assert_same(exp, got[i], recs, "in flight %d" % i)
+    finally:
+        other.close()
