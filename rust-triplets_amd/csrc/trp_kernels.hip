@@ -441,7 +441,12 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
     const PadBlk blk = lane_block(sh, tid);
     L.p = tS + (u64)tid * BLOCK;
     L.nvalid = L.p >= N ? 0 : (int)((N - L.p) < (u64)BLOCK ? (N - L.p) : (u64)BLOCK);
-    L.c = classify_block_fast(blk, L.nvalid, ut);
+    if (normalize || !want_lines) {   // these modes look at whitespace only
+        Cls z = {classify_ws_fast(blk, L.nvalid), 0, 0, 0, 0, 0, 0};
+        L.c = z;
+    } else {
+        L.c = classify_block_fast(blk, L.nvalid, ut);
+    }
     u64 V = below(L.nvalid);
     u64 RS = rs_here & V;
     bool nrs = (rs_next & 1ull) != 0;
@@ -485,9 +490,10 @@ __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, 
 // k_summary: per-tile forward summary (line statistics at the tile edges, record-level alpha flags).
 // ---------------------------------------------------------------------------------------------------
 constexpr int SUM_TPW = 1;   // consecutive tiles per workgroup (the next one is loaded during the current one)
+template <bool NORMALIZE>
 __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                                  const u32* __restrict__ rec_lo, u64 R, u64 N,
-                                                 u64 nB, u64 nT, u32 normalize, J* __restrict__ SA) {
+                                                 u64 nB, u64 nT, J* __restrict__ SA) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ J wsum[NT / 64];
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, co
         rs_store(rf, offsets, rec_lo, R, N, t, rs);
         __syncthreads();
         LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs.w[threadIdx.x], rs.w[threadIdx.x + 1],
-                               normalize != 0);
+                               NORMALIZE);
         // the next tile's loads are issued after the register-hungry classification
         if (i + 1 < SUM_TPW && t + 1 < nT) {
             tile_load(bytes, N, tS + TILE, regs);
@@ -844,6 +850,7 @@ struct PlanShared {
 };
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 
+template <bool NORMALIZE>
 __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     if (tid == 64) sh.seed_s = seedS[t];
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
-    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w[tid], sh.rs.w[tid + 1], cfg.normalize != 0);
+    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w[tid], sh.rs.w[tid + 1], NORMALIZE);
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
     const WaveLines W = wave_lines(lane_J(L.c, L.d));
     {
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
-    Plan pl = cfg.normalize ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok) : plan_block(L.c, L.d, k, cfg);
+    Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok) : plan_block(L.c, L.d, k, cfg);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -1385,7 +1392,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
     // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every tile after that phase
     if (stop_after == 1) { __syncthreads(); continue; }
     if (PASSTHROUGH) {
-        Cls c = classify_block_fast(blk, nvalid, dev_tables());
+        Cls c = {classify_ws_fast(blk, nvalid), 0, 0, 0, 0, 0, 0};
         pl = plan_passthrough(c, V);
         if (tid == 0 && b > 0) edge_prev = !byte_is_ws(blk, -1);
         if (tid == NT - 1 && p + BLOCK < N) edge_next = !byte_is_ws(blk, BLOCK);
@@ -1997,8 +2004,9 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if (nT) {
         if (!pass) {
             { Prof pr(c, "k_summary");
-              hipLaunchKernelGGL(k_summary, dim3((unsigned)((nT + SUM_TPW - 1) / SUM_TPW)), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
-                                 nT, dc.normalize, SA); }
+              const dim3 grid((unsigned)((nT + SUM_TPW - 1) / SUM_TPW));
+              if (dc.normalize) hipLaunchKernelGGL(k_summary<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, SA);
+              else hipLaunchKernelGGL(k_summary<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, SA); }
             { Prof pr(c, "k_tile_carry");
               u32* far_count = reinterpret_cast<u32*>(totals + 7);   // zeroed with the totals
               hipLaunchKernelGGL(k_tile_carry_near, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, SA, nT,
@@ -2006,9 +2014,14 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
               hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 4096)), dim3(NT), 0, st,
                                  SA, nT, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count); }
             { Prof pr(c, "k_plan");
-              hipLaunchKernelGGL(k_plan, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, c->seedJ.as<J>(),
-                                 c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes, ttoks, tflags,
-                                 c->plan_stop()); }
+              if (dc.normalize)
+                  hipLaunchKernelGGL(k_plan<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
+                                     c->seedJ.as<J>(), c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes,
+                                     ttoks, tflags, c->plan_stop());
+              else
+                  hipLaunchKernelGGL(k_plan<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
+                                     c->seedJ.as<J>(), c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes,
+                                     ttoks, tflags, c->plan_stop()); }
             { Prof pr(c, "k_gate3");
               hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
                                  c->g3list.as<u64>(), totals + 6, g3_cap, tbytes, ttoks, totals); }

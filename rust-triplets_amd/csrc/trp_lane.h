@@ -267,6 +267,69 @@ TRP_UNROLL
     }
 }
 
+// Multi-byte characters of the common scripts, classified for half a block at once from the bit planes
+// (no byte access, no table).  p[k]: bit plane k of the 32 bytes of the half; q[k]: the same plane of the
+// 32 bytes that follow (sequences may run over).  `lead`: lead bytes (11xxxxxx) of the half whose sequence
+// ends inside the block.  ORs the alphabetic ones into *alp and returns the ones it has settled
+// (alphabetic, or neither alphabetic nor whitespace).  Everything else - other scripts, whitespace
+// characters, sequences that cross the block edge, malformed bytes - stays for the per-character path.
+// Each rule is a range of code points that is uniformly Alphabetic (or uniformly neither class) in the
+// table; a test compares the two paths for every code point.
+TRP_HD u32 funnel_shr(u32 hi, u32 lo, int n) { return (u32)((((u64)hi << 32) | lo) >> n); }
+TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead, u32* alp) {
+    if (!lead) return 0;
+    const u32 cont = p[7] & ~p[6], contq = q[7] & ~q[6];
+    const u32 v1 = funnel_shr(contq, cont, 1), v2 = funnel_shr(contq, cont, 2), v3 = funnel_shr(contq, cont, 3);
+    const u32 l0 = p[0], l1 = p[1], l2 = p[2], l3 = p[3], l4 = p[4];
+    // low six bits of the second (x) and third (y) byte, aligned to the lead byte
+    const u32 x0 = funnel_shr(q[0], p[0], 1), x1 = funnel_shr(q[1], p[1], 1), x2 = funnel_shr(q[2], p[2], 1),
+              x3 = funnel_shr(q[3], p[3], 1), x4 = funnel_shr(q[4], p[4], 1), x5 = funnel_shr(q[5], p[5], 1);
+    const u32 x_ge16 = x5 | x4;
+    u32 settled = 0, alpha = 0;
+    const u32 L2 = lead & ~p[5] & v1;   // 110xxxxx 10xxxxxx
+    if (L2) {
+        const u32 lo = L2 & ~l4, hi = L2 & l4 & ~l3;                                // leads C0-CF, D0-D7
+        const u32 C3 = lo & ~l3 & ~l2 & l1 & l0;                                    // U+00C0-00FF
+        const u32 C4_CA = lo & ((~l3 & l2) | (l3 & ~l2 & ~(l1 & l0)));              // U+0100-02BF
+        const u32 CE = lo & l3 & l2 & l1 & ~l0, CF = lo & l3 & l2 & l1 & l0;        // U+0380-03BF, 03C0-03FF
+        const u32 D013 = hi & ~l2 & (~l1 | l0);                                     // U+0400-047F, 04C0-04FF
+        const u32 D2 = hi & ~l2 & l1 & ~l0;                                         // U+0480-04BF
+        const u32 D4 = hi & l2 & ~l1 & ~l0;                                         // U+0500-053F
+        const u32 x17 = x4 & ~x3 & x2 & x1 & x0;                                    // U+00D7, U+00F7
+        const u32 x22 = x5 & ~x4 & ~x3 & ~x2 & x1 & ~x0;                            // U+03A2
+        const u32 x36 = x5 & x4 & ~x3 & x2 & x1 & ~x0;                              // U+03F6
+        const u32 x30 = x5 & x4 & ~x3 & ~x2 & ~x1 & ~x0;                            // U+0530
+        settled |= C3 | C4_CA | (CE & x_ge16) | CF | D013 | (D2 & x_ge16) | D4;
+        alpha |= (C3 & ~x17) | C4_CA | (CE & x_ge16 & ~x22) | (CF & ~x36) | D013 | (D2 & x_ge16) | (D4 & ~x30);
+    }
+    const u32 L3 = lead & p[5] & ~p[4] & v1 & v2;   // 1110xxxx 10xxxxxx 10xxxxxx
+    const u32 L4 = lead & p[5] & p[4] & ~p[3] & v1 & v2 & v3;
+    if (L3 | L4) {
+        const u32 y0 = funnel_shr(q[0], p[0], 2), y1 = funnel_shr(q[1], p[1], 2), y2 = funnel_shr(q[2], p[2], 2),
+                  y3 = funnel_shr(q[3], p[3], 2), y4 = funnel_shr(q[4], p[4], 2), y5 = funnel_shr(q[5], p[5], 2);
+        const u32 E5_E9 = L3 & ((~l3 & l2 & (l1 | l0)) | (l3 & ~l2 & ~l1));         // U+5000-9FFF
+        const u32 E4 = L3 & ~l3 & l2 & ~l1 & ~l0;                                   // U+4000-4FFF
+        const u32 E3 = L3 & ~l3 & ~l2 & l1 & l0;                                    // U+3000-3FFF
+        const u32 EB_EC = L3 & l3 & ((~l2 & l1 & l0) | (l2 & ~l1 & ~l0));           // U+B000-CFFF
+        const u32 EA = L3 & l3 & ~l2 & l1 & ~l0;                                    // U+A000-AFFF
+        const u32 ED = L3 & l3 & l2 & ~l1 & l0;                                     // U+D000-DFFF
+        const u32 E2 = L3 & ~l3 & ~l2 & l1 & ~l0;                                   // U+2000-2FFF
+        const u32 x37 = x5 & x4 & ~x3 & x2 & x1 & x0;                               // U+4DC0-4DFF
+        const u32 x_lt1E = ~x5 & ~(x4 & x3 & x2 & x1);                              // U+D000-D77F
+        const u32 x00 = ~(x5 | x4 | x3 | x2 | x1 | x0), x02 = ~(x5 | x4 | x3 | x2 | x0) & x1;
+        const u32 y_ws = y5 & ~y4 & y3 & ((~y2 & ~y1) | (y2 & y1 & y0));            // U+2028, 2029, 202F
+        // U+2010-203F without the three whitespace characters, U+20A0-20BF: punctuation and currency signs
+        const u32 E2_none = E2 & ((x00 & (y5 | y4) & ~y_ws) | (x02 & y5));
+        // U+1F300-1FFFF: pictographs, no letters
+        const u32 F0_9F = L4 & ~l2 & ~l1 & ~l0 & ~x5 & x4 & x3 & x2 & x1 & x0 & (y5 | y4 | (y3 & y2));
+        const u32 a3 = E5_E9 | (E4 & ~x37) | (E3 & x_ge16) | EB_EC | (EA & x5 & x4) | (ED & x_lt1E);
+        settled |= a3 | E4 | E2_none | F0_9F;
+        alpha |= a3;
+    }
+    *alp |= alpha;
+    return settled;
+}
+
 template <class B>
 TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut) {
     u32 w[16];
@@ -275,26 +338,24 @@ TRP_UNROLL
     u64 b[8];
     transpose_block(w, b);
     const u64 V = below(nvalid);
-    const u64 n7 = ~b[7] & V;
-    const u64 lowq = n7 & ~b[6] & ~b[5] & ~b[4];                 // 0x00-0x0F
-    const u64 ctl = lowq & b[3];                                 // 0x08-0x0F
-    Cls c;
-    c.nl = ctl & ~b[2] & b[1] & ~b[0];                           // 0x0A
-    c.cr = ctl & b[2] & ~b[1] & b[0];                            // 0x0D
-    const u64 wsc = ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1]); // 0x09-0x0D
-    const u64 sp = n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]);   // 0x20
-    c.ws = wsc | sp;
-    c.sp = sp;
-    c.dig = n7 & ~b[6] & b[5] & b[4] & ~(b[3] & (b[2] | b[1]));  // 0x30-0x39
-    const u64 nz5 = b[4] | b[3] | b[2] | b[1] | b[0];
-    const u64 gt26 = b[4] & b[3] & (b[2] | (b[1] & b[0]));
-    c.alp = n7 & b[6] & nz5 & ~gt26;                             // A-Z a-z
-    c.pipe = n7 & b[6] & b[5] & b[4] & b[3] & b[2] & ~b[1] & ~b[0];   // 0x7C
-    // Bytes >= 0x80.  Only lead bytes (11xxxxxx) are decoded; a whitespace character marks all its
-    // bytes, an alphabetic one its lead byte.  Continuation bytes at the very start of the block
-    // belong to a character that began in the previous block and are resolved by looking back.
+    // Bytes >= 0x80 first (few values are live here).  Only lead bytes (11xxxxxx) are decoded; a
+    // whitespace character marks all its bytes, an alphabetic one its lead byte.  Continuation bytes at
+    // the very start of the block belong to a character that began in the previous block and are resolved
+    // by looking back.
+    u64 mb_ws = 0, mb_alp = 0;
     const u64 high = b[7] & V;
     u64 lead = high & b[6];
+    if (lead) {
+        // the common scripts from the bit planes, half a block at a time
+        u32 lo[8], hi[8], zero[8];
+TRP_UNROLL
+        for (int k = 0; k < 8; k++) { lo[k] = (u32)b[k]; hi[k] = (u32)(b[k] >> 32); zero[k] = 0; }
+        u32 alp_lo = 0, alp_hi = 0;
+        const u32 s_lo = classify_leads_planes(lo, hi, (u32)lead, &alp_lo);
+        const u32 s_hi = classify_leads_planes(hi, zero, (u32)(lead >> 32) & 0x1FFFFFFFu, &alp_hi);   // ends by byte 63
+        mb_alp = (u64)alp_lo | ((u64)alp_hi << 32);
+        lead &= ~((u64)s_lo | ((u64)s_hi << 32));
+    }
     while (lead) {
         const int j = ctz(lead);
         lead &= lead - 1;
@@ -304,22 +365,22 @@ TRP_UNROLL
         if ((b1 & 0xC0u) != 0x80u) continue;
         if (b0 < 0xE0u) {
             const u32 cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
-            if (cp == 0x85u || cp == 0xA0u) c.ws |= (3ull << j) & V;
-            else if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
+            if (cp == 0x85u || cp == 0xA0u) mb_ws |= (3ull << j) & V;
+            else if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
             continue;
         }
         const u32 b2 = blk[j + 2];
         if ((b2 & 0xC0u) != 0x80u) continue;
         if (b0 < 0xF0u) {
             const u32 cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
-            if (b0 <= 0xE3u && b0 != 0xE0u && cp_is_ws_high(cp)) c.ws |= (7ull << j) & V;
-            else if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
+            if (b0 <= 0xE3u && b0 != 0xE0u && cp_is_ws_high(cp)) mb_ws |= (7ull << j) & V;
+            else if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
             continue;
         }
         const u32 b3 = blk[j + 3];
         if ((b3 & 0xC0u) != 0x80u) continue;
         const u32 cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
-        if (cp_is_alpha_high(cp, ut)) c.alp |= bit(j);
+        if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
     }
     u64 head = high & ~b[6] & 7ull;   // continuation bytes among the first three
     for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
@@ -328,13 +389,77 @@ TRP_UNROLL
             u32 l = blk[j - k];
             if (l >= 0xC0) {
                 int n = decode_lead(blk, j - k, &cp);
-                if (n > k && cp_is_ws_high(cp)) c.ws |= bit(j);
+                if (n > k && cp_is_ws_high(cp)) mb_ws |= bit(j);
                 break;
             }
             if (l < 0x80) break;
         }
     }
+    // ASCII classes: boolean formulas over the planes
+    const u64 n7 = ~b[7] & V;
+    const u64 lowq = n7 & ~b[6] & ~b[5] & ~b[4];                 // 0x00-0x0F
+    const u64 ctl = lowq & b[3];                                 // 0x08-0x0F
+    Cls c;
+    c.nl = ctl & ~b[2] & b[1] & ~b[0];                           // 0x0A
+    c.cr = ctl & b[2] & ~b[1] & b[0];                            // 0x0D
+    const u64 wsc = ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1]); // 0x09-0x0D
+    const u64 sp = n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]);   // 0x20
+    c.ws = wsc | sp | mb_ws;
+    c.sp = sp;
+    c.dig = n7 & ~b[6] & b[5] & b[4] & ~(b[3] & (b[2] | b[1]));  // 0x30-0x39
+    const u64 nz5 = b[4] | b[3] | b[2] | b[1] | b[0];
+    const u64 gt26 = b[4] & b[3] & (b[2] | (b[1] & b[0]));
+    c.alp = (n7 & b[6] & nz5 & ~gt26) | mb_alp;                  // A-Z a-z
+    c.pipe = n7 & b[6] & b[5] & b[4] & b[3] & b[2] & ~b[1] & ~b[0];   // 0x7C
     return c;
+}
+
+// The whitespace mask alone (what the pass-through configuration needs): no Alphabetic lookups at all.
+// Only the lead bytes C2, E1, E2 and E3 can begin a whitespace character.
+template <class B>
+TRP_HD u64 classify_ws_fast(const B& blk, int nvalid) {
+    u32 w[16];
+TRP_UNROLL
+    for (int k = 0; k < 16; k++) w[k] = blk.word(k);
+    u64 b[8];
+    transpose_block(w, b);
+    const u64 V = below(nvalid);
+    const u64 n7 = ~b[7] & V;
+    const u64 ctl = n7 & ~b[6] & ~b[5] & ~b[4] & b[3];
+    u64 ws = (ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1])) |
+             (n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]));
+    const u64 high = b[7] & V;
+    const u64 z432 = ~(b[4] | b[3] | b[2]);
+    u64 lead = high & b[6] & z432 & ((~b[5] & b[1] & ~b[0]) | (b[5] & (b[1] | b[0])));   // C2 | E1..E3
+    while (lead) {
+        const int j = ctz(lead);
+        lead &= lead - 1;
+        const u32 b0 = blk[j], b1 = blk[j + 1];
+        if ((b1 & 0xC0u) != 0x80u) continue;
+        if (b0 < 0xE0u) {
+            const u32 cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+            if (cp == 0x85u || cp == 0xA0u) ws |= (3ull << j) & V;
+            continue;
+        }
+        const u32 b2 = blk[j + 2];
+        if ((b2 & 0xC0u) != 0x80u) continue;
+        const u32 cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+        if (cp_is_ws_high(cp)) ws |= (7ull << j) & V;
+    }
+    u64 head = high & ~b[6] & 7ull;   // continuation bytes among the first three
+    for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
+        u32 cp;
+        for (int k = j + 1; k <= 3; k++) {   // the lead byte is before the block
+            u32 l = blk[j - k];
+            if (l >= 0xC0) {
+                int n = decode_lead(blk, j - k, &cp);
+                if (n > k && cp_is_ws_high(cp)) ws |= bit(j);
+                break;
+            }
+            if (l < 0x80) break;
+        }
+    }
+    return ws;
 }
 
 // Is the byte q[at] part of a whitespace character?  q[at-3..at+3] must be readable.

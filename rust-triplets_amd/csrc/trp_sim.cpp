@@ -142,7 +142,8 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
             bool next_nl = (p + 64 < N) && base[p + 64] == '\n' && !rs_at(p + 64);
             bool pt = prev_is_term(p > 0, p > 0 ? base[p - 1] : 0, true, base[p], rs_at(p));
             if (cfg.normalize) {
-                cls[b] = normalize_cls(cls[b], Vm[b]);
+                Cls zw = {classify_ws_fast(PlainBlk{base + p}, (int)(N - p < 64 ? N - p : 64)), 0, 0, 0, 0, 0, 0};
+                cls[b] = normalize_cls(zw, Vm[b]);
                 next_nl = pt = false;
             }
             der[b] = derive(cls[b], Vm[b], RSw[b], next_nl, pt);
@@ -246,7 +247,12 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
             }
         }
     } else {
-        for (u64 b = 0; b < nB; b++) plan[b] = plan_passthrough(cls[b], Vm[b]);
+        for (u64 b = 0; b < nB; b++) {   // whitespace from the mask-only classifier, as on the device
+            Cls cw = cls[b];
+            const u64 p = b * 64;
+            cw.ws = classify_ws_fast(PlainBlk{base + p}, (int)(N - p < 64 ? N - p : 64));
+            plan[b] = plan_passthrough(cw, Vm[b]);
+        }
     }
 
     // interpret the plan
@@ -352,6 +358,38 @@ extern "C" int trp_sim_check_alpha_shortcut() {
         for (int i = 0; i < 64; i++) low[i] = trp_alpha_stage2[trp_alpha_stage1[i >> 3] * 8 + (i & 7)];
         UniTables ul = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, low};
         if (t != cp_is_alpha_high(cp, ul)) bad++;
+    }
+    return bad;
+}
+
+// classify_block_fast (bit planes, range rules for the common scripts) against classify_block (one byte
+// at a time, table only) for every code point at several positions of a block, including positions where
+// the sequence crosses the end of the block.  Returns the number of differing blocks.
+extern "C" int trp_sim_check_classify_codepoints() {
+    UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
+    int bad = 0;
+    u8 buf[8 + 64 + 8];
+    static const int positions[] = {0, 33, 58, 60, 61, 62, 63};
+    for (u32 cp = 0x80; cp < 0x110000; cp++) {
+        if (cp >= 0xD800 && cp < 0xE000) continue;
+        if (cp >= 0x40000 && cp % 7u) continue;   // nothing is assigned there but the tag and selector blocks
+        u8 enc[4];
+        int n;
+        if (cp < 0x800) { enc[0] = 0xC0 | (cp >> 6); enc[1] = 0x80 | (cp & 63); n = 2; }
+        else if (cp < 0x10000) { enc[0] = 0xE0 | (cp >> 12); enc[1] = 0x80 | ((cp >> 6) & 63); enc[2] = 0x80 | (cp & 63); n = 3; }
+        else { enc[0] = 0xF0 | (cp >> 18); enc[1] = 0x80 | ((cp >> 12) & 63); enc[2] = 0x80 | ((cp >> 6) & 63); enc[3] = 0x80 | (cp & 63); n = 4; }
+        for (int pos : positions) {
+            for (int fill = 0; fill < 2; fill++) {
+                // surroundings: ASCII, or copies of the character itself (adjacent multi-byte sequences)
+                for (int i = 0; i < (int)sizeof(buf); i++) buf[i] = fill ? enc[(i + 4 * n - (8 + pos) % n) % n] : (u8)('a' + i % 3);
+                for (int i = 0; i < n; i++) buf[8 + pos + i] = enc[i];
+                const PlainBlk blk = {buf + 8};
+                const Cls f = classify_block_fast(blk, 64, ut), r = classify_block(blk, 64, ut);
+                if (f.ws != r.ws || f.alp != r.alp || f.nl != r.nl || f.cr != r.cr || f.pipe != r.pipe || f.dig != r.dig)
+                    bad++;
+                if (classify_ws_fast(blk, 64) != r.ws) bad++;
+            }
+        }
     }
     return bad;
 }

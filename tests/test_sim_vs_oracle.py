@@ -27,6 +27,10 @@ def test_alpha_range_shortcut_matches_table():
     assert S.lib().trp_sim_check_alpha_shortcut() == 0
 
 
+def test_plane_rules_match_table_for_every_code_point():
+    assert S.lib().trp_sim_check_classify_codepoints() == 0
+
+
 def test_monoids_are_associative():
     assert S.lib().trp_sim_check_monoids(12345, 200000) == 0
 
