@@ -59,8 +59,9 @@ def main():
     ap.add_argument("--normalize", action="store_true",
                     help="time normalize_inline_whitespace (the step before the path) instead of the path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--blocking", action="store_true",
-                    help="time blocking calls on one context instead of batches in flight on two")
+    ap.add_argument("--in-flight", action="store_true",
+                    help="keep one batch in flight on each of two contexts (trp_submit_batch_device / "
+                         "trp_wait_batch) instead of timing blocking calls on one context")
     ap.add_argument("--host-path", action="store_true",
                     help="also time trp_preprocess_batch on host buffers (PCIe both ways included)")
     args = ap.parse_args()
@@ -146,10 +147,11 @@ def main():
                 after_batch()
         return d, t, c
 
-    # Timed region: batches are kept in flight on two contexts (two sets of result buffers, one stream
-    # each) the way a consumer of one batch overlaps with the production of the next; every batch of every
-    # step is waited for inside the region.  --blocking times back-to-back blocking calls on one context.
-    ctx2 = None if (args.blocking or args.normalize) else T.Context(device)
+    # Timed region: back-to-back blocking calls on one context (each returns after its kernels have
+    # completed).  With --in-flight, batches are kept in flight on two contexts (two sets of result buffers,
+    # one stream each) the way a consumer of one batch overlaps with the production of the next; every
+    # batch of every step is still waited for inside the region.
+    ctx2 = T.Context(device) if (args.in_flight and not args.normalize) else None
 
     def run_steps(k):
         """k passes over the shard; returns the (denoised bytes, tokens, chunks) of the last pass."""
