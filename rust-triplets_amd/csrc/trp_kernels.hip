@@ -431,6 +431,7 @@ struct LaneCtx {
     int nvalid;
     bool next_rs;   // the byte after the block starts a record or does not exist
     bool prev_tok;  // normalize mode: the byte before the block is a token byte of the same record
+    u64 sp, nl;     // bytes that are exactly ' ' / '\n' (for plan_fold_prefixes)
 };
 
 // rs_here / rs_next: record-start words of this block and of the next one (RsShared).
@@ -442,10 +443,13 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
     L.p = tS + (u64)tid * BLOCK;
     L.nvalid = L.p >= N ? 0 : (int)((N - L.p) < (u64)BLOCK ? (N - L.p) : (u64)BLOCK);
     if (normalize || !want_lines) {   // these modes look at whitespace only
-        Cls z = {classify_ws_fast(blk, L.nvalid), 0, 0, 0, 0, 0, 0};
+        Cls z = {classify_ws_fast(blk, L.nvalid, &L.sp), 0, 0, 0, 0, 0, 0};
         L.c = z;
+        L.nl = 0;
     } else {
         L.c = classify_block_fast(blk, L.nvalid, ut);
+        L.sp = L.c.sp;
+        L.nl = L.c.nl;
     }
     u64 V = below(L.nvalid);
     u64 RS = rs_here & V;
@@ -851,7 +855,7 @@ struct PlanShared {
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
                                               Plan* __restrict__ plan, u64* __restrict__ g3list, u64 g3cap,
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
-    Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok) : plan_block(L.c, L.d, k, cfg);
+    Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp) : plan_block(L.c, L.d, k, cfg);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -915,6 +919,11 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
         gm.ls[tid] = L.d.LS;
         gm.G[tid] = 0; gm.gPSP[tid] = 0; gm.gPNL[tid] = 0;
         sh.marks[tid] = marks;
+        // parked in LDS across the solve (registers are short there): the ' ' and '\n' masks.  Both arrays
+        // are free here: the record starts were consumed by lane_setup before the barriers above, the
+        // token masks are written after the plan is stored.
+        sh.tokc[tid] = L.sp;
+        sh.rs.w[tid] = L.nl;
         u32 nm = popc(marks), tot = 0;
         u32 at = block_scan_excl_fwd(nm, U32Add(), 0u, 0u, sh.scan32, &tot);   // ends with a barrier
         if (tot > 0) {   // uniform
@@ -940,6 +949,7 @@ __global__ __launch_bounds__(NT) void k_plan(const u8* __restrict__ bytes, const
             pl.C |= gm.G[tid];
             pl.TOK |= gm.G[tid];
             marks = left;
+            plan_fold_prefixes(pl, sh.tokc[tid], sh.rs.w[tid], below(L.nvalid));   // the separators of the kept tokens
         }
     }
     if (stop_after == 5) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }

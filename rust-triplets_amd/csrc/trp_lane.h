@@ -417,7 +417,7 @@ TRP_UNROLL
 // The whitespace mask alone (what the pass-through configuration needs): no Alphabetic lookups at all.
 // Only the lead bytes C2, E1, E2 and E3 can begin a whitespace character.
 template <class B>
-TRP_HD u64 classify_ws_fast(const B& blk, int nvalid) {
+TRP_HD u64 classify_ws_fast(const B& blk, int nvalid, u64* sp = nullptr) {
     u32 w[16];
 TRP_UNROLL
     for (int k = 0; k < 16; k++) w[k] = blk.word(k);
@@ -426,8 +426,9 @@ TRP_UNROLL
     const u64 V = below(nvalid);
     const u64 n7 = ~b[7] & V;
     const u64 ctl = n7 & ~b[6] & ~b[5] & ~b[4] & b[3];
-    u64 ws = (ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1])) |
-             (n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]));
+    const u64 space = n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]);   // 0x20
+    if (sp) *sp = space;
+    u64 ws = (ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1])) | space;
     const u64 high = b[7] & V;
     const u64 z432 = ~(b[4] | b[3] | b[2]);
     u64 lead = high & b[6] & z432 & ((~b[5] & b[1] & ~b[0]) | (b[5] & (b[1] | b[0])));   // C2 | E1..E3
@@ -685,6 +686,20 @@ struct LaneCarry {
 };
 
 // ---- normalize_inline_whitespace (src/utils.rs:18-33) on the same machinery ------------------------
+// Canonical form of a plan: a separator that is emitted in front of byte j while byte j-1 is dropped and
+// happens to be that very character ('\n' terminator before a kept line, single space before a table
+// cell or a kept token) is expressed as "copy byte j-1" instead.  Same output bytes, longer copy runs.
+// Only where the prefixed byte itself is copied (not the marker of an unsolved digit-heavy line).
+TRP_HD void plan_fold_prefixes(Plan& p, u64 sp, u64 nl, u64 V) {
+    u64 cn = (p.PNL >> 1) & ~p.C & nl & V;
+    u64 cs = (p.PSP >> 1) & ~p.C & sp & V & ~(p.PNL >> 1);
+    cn &= (p.C >> 1);
+    cs &= (p.C >> 1);
+    p.C |= cn | cs;
+    p.PNL &= ~(cn << 1);
+    p.PSP &= ~(cs << 1);
+}
+
 // The reference collapses every run of White_Space characters into one ' ' and trims the result, i.e.
 // the output is the record's whitespace-separated tokens joined by single spaces.  As an emit plan:
 // copy the token bytes, and put one ' ' in front of every token start except the first of its record.
@@ -696,7 +711,8 @@ TRP_HD Cls normalize_cls(const Cls& c, u64 V) {
     return n;
 }
 // prev_tok: the byte before the block exists, belongs to the same record and is not whitespace.
-TRP_HD Plan plan_normalize(const Cls& c, const Derived& d, bool ar_in, bool prev_tok) {
+// sp: the bytes that are exactly 0x20.
+TRP_HD Plan plan_normalize(const Cls& c, const Derived& d, bool ar_in, bool prev_tok, u64 sp) {
     const u64 T = d.V & ~c.ws;
     const u64 TS = T & (~((T << 1) | (prev_tok ? 1ull : 0ull)) | d.RS);
     u64 first = 0;   // the first token start of every record that starts in, or reaches, this block
@@ -711,6 +727,7 @@ TRP_HD Plan plan_normalize(const Cls& c, const Derived& d, bool ar_in, bool prev
         first |= x & (0ull - x);
     }
     Plan p = {T, T, TS & ~first, 0};
+    plan_fold_prefixes(p, sp, 0, d.V);
     return p;
 }
 
@@ -800,18 +817,7 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         s = e;
         is_head = false;
     }
-    // Canonical form: a separator that is emitted in front of byte j while byte j-1 is dropped and
-    // happens to be that very character ('\n' terminator before a kept line, single space before a
-    // table cell) is expressed as "copy byte j-1" instead.  Same output bytes, longer copy runs.
-    {
-        u64 cn = (out.PNL >> 1) & ~out.C & c.nl & d.V;
-        u64 cs = (out.PSP >> 1) & ~out.C & c.sp & d.V & ~(out.PNL >> 1);
-        cn &= (out.C >> 1);   // only where the prefixed byte itself is copied (not a gate-3 marker)
-        cs &= (out.C >> 1);
-        out.C |= cn | cs;
-        out.PNL &= ~(cn << 1);
-        out.PSP &= ~(cs << 1);
-    }
+    plan_fold_prefixes(out, c.sp, c.nl, d.V);
     return out;
 }
 

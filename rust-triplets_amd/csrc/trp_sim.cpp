@@ -137,13 +137,16 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
     if (cfg.denoise_enabled) {
         std::vector<Derived> der(nB);
         std::vector<J> jl(nB);
+        std::vector<u64> spm(nB, 0);
         for (u64 b = 0; b < nB; b++) {
             u64 p = b * 64;
             bool next_nl = (p + 64 < N) && base[p + 64] == '\n' && !rs_at(p + 64);
             bool pt = prev_is_term(p > 0, p > 0 ? base[p - 1] : 0, true, base[p], rs_at(p));
             if (cfg.normalize) {
-                Cls zw = {classify_ws_fast(PlainBlk{base + p}, (int)(N - p < 64 ? N - p : 64)), 0, 0, 0, 0, 0, 0};
+                u64 space = 0;
+                Cls zw = {classify_ws_fast(PlainBlk{base + p}, (int)(N - p < 64 ? N - p : 64), &space), 0, 0, 0, 0, 0, 0};
                 cls[b] = normalize_cls(zw, Vm[b]);
+                spm[b] = space;
                 next_nl = pt = false;
             }
             der[b] = derive(cls[b], Vm[b], RSw[b], next_nl, pt);
@@ -184,7 +187,7 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                 if (cfg.normalize) {
                     u64 p = b * 64;
                     bool prev_tok = p > 0 && !rs_at(p) && !byte_is_ws(PlainBlk{base + p}, -1);
-                    plan[b] = plan_normalize(cls[b], der[b], k.ar_in, prev_tok);
+                    plan[b] = plan_normalize(cls[b], der[b], k.ar_in, prev_tok, spm[b]);
                 } else {
                     plan[b] = plan_block(cls[b], der[b], k, cfg);
                 }
