@@ -237,3 +237,12 @@ def test_submit_and_wait_on_two_contexts(T, ctx):
             assert_same(exp, got[i], recs, "in flight %d" % i)
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_scripts_and_rule_boundaries(T, ctx, seed):
+    """Many scripts and the characters at the edges of the classifier's range rules, all modes."""
+    recs = textgen.script_corpus(800 + seed, 400)
+    for cfg in ((True, 0.35, True, 12, (3,), 4), (True, 0.8, False, 1024, (64,), 512), (False, 0.35, True, 12, (3,), 4)):
+        exp, got = _run(T, ctx, recs, cfg)
+        assert_same(exp, got, recs, "scripts%d" % seed)

@@ -75,7 +75,7 @@ def sim_normalize(records, tile_blocks):
 
 @pytest.mark.parametrize("tile_blocks", [1, 2, 3, 256])
 def test_simulator_matches_oracle(tile_blocks):
-    for recs in (EDGE, textgen.corpus(17, 300), [b"".join(EDGE)]):
+    for recs in (EDGE, textgen.corpus(17, 300), [b"".join(EDGE)], textgen.script_corpus(18, 150)):
         norm, exp = expected(recs)
         got = sim_normalize(recs, tile_blocks)
         assert_same(exp, got, recs, "normalize sim tile_blocks=%d" % tile_blocks)
@@ -84,7 +84,7 @@ def test_simulator_matches_oracle(tile_blocks):
 @pytest.mark.gpu
 def test_gpu_matches_oracle():
     ctx = T.Context(0)
-    for recs in (EDGE, textgen.corpus(17, 2000), [b"".join(EDGE)], [], [b""]):
+    for recs in (EDGE, textgen.corpus(17, 2000), [b"".join(EDGE)], [], [b""], textgen.script_corpus(18, 600)):
         norm, exp = expected(recs)
         data, offs = O.pack(recs)
         got = ctx.normalize_batch(data, offs)

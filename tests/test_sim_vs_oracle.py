@@ -72,3 +72,12 @@ def test_edge_batches():
         data, offs = O.pack(recs)
         for tb in (1, 256):
             assert_same(O.batch(data, offs, cfg), S.batch(data, offs, cfg, tb), recs, repr(recs)[:60])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_scripts_and_rule_boundaries(seed):
+    recs = textgen.script_corpus(700 + seed, 150)
+    data, offs = O.pack(recs)
+    for enabled, ratio, md in ((True, 0.35, True), (True, 0.8, False), (False, 0.35, True)):
+        cfg = O.make_config(enabled, ratio, md, 12, (3,), 4)
+        assert_same(O.batch(data, offs, cfg), S.batch(data, offs, cfg, [1, 4, 256][seed % 3]), recs, "scripts%d" % seed)

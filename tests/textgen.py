@@ -92,3 +92,31 @@ def corpus(seed, n_records, max_lines=12):
         else:
             recs.append(record(rng, max_lines))
     return recs
+
+
+# Words in many scripts plus characters at the edges of the ranges that the GPU classifier settles from
+# bit planes (letters next to symbols of the same block, unassigned code points, pictographs with and
+# without the Alphabetic property, every White_Space character).
+SCRIPT_WORDS = ["прибыль", "Ёж", "ҐґҒ", "\u0482\u0483", "Ԁԯ", "\u0530", "Աբգ", "Ֆ\u0557ՙ", "×", "÷", "ÀÖØöøÿ", "ĀſƀɏɐʯʰˁDŽ",
+                "\u02c2\u02c5ˆ", "ΆΈΊΌΎΡ\u03a2Σ", "ϵ϶Ϸ", "\u0378\u0384·", "שלום", "\u05be\u05c0", "سلام", "٠١٢", "ۿ۽",
+                "हिन्दी", "ไทย", "ひらがな", "カタカナ", "・ー", "\u3040\u3097", "㐀䶿", "䷀䷿", "一鿿", "ꀀ꒍", "가힣", "\ud7a4\ud7b0ퟻ",
+                "한국어", "🄰🅉🅰", "🈀🌀🚀🫸", "\U0001fbf0", "𐀀𐌀", "𠀀𪛟", "\U0002fa1d\U0003134a", "—–‘’“”•…", "€₠⃀", "ⁱⁿ₀ₐ", "ℂ℃ℊ",
+                "a\u00a0b", "c\u1680d", "e\u2000f\u200ag", "h\u2028i\u2029j", "k\u202fl\u205fm", "n\u3000o", "p\u0085q",
+                "\u200b\u200e", "\ufeffBOM", "ｆｕｌｌ", "ﬁﬂ", "𝐀𝑏𝒸"]
+
+
+def script_corpus(seed, n_records):
+    """Records whose lines mix SCRIPT_WORDS with numbers so that all three gates see them."""
+    rng = random.Random(seed)
+    recs = []
+    for _ in range(n_records):
+        lines = []
+        for _ in range(rng.randint(1, 8)):
+            toks = []
+            for _ in range(rng.randint(1, 16)):
+                k = rng.random()
+                toks.append(rng.choice(SCRIPT_WORDS) if k < 0.6 else rng.choice(NUMS) if k < 0.9 else rng.choice(WORDS))
+            line = rng.choice(["", " ", "| "]) + rng.choice([" ", " ", " | ", "\t"]).join(toks) + rng.choice(["", " |", " "])
+            lines.append(line)
+        recs.append(rng.choice(EOLS[:5]).join(lines).encode("utf-8"))
+    return recs
