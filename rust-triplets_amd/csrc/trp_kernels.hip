@@ -201,42 +201,48 @@ __device__ inline WaveLines wave_lines(const J& j) {
     return W;
 }
 
-// The summary of the whole wave (uniform); equals the ordered fold of j_combine over the lanes.
-__device__ inline J wave_total(const WaveLines& W) {
+// The summary of the lanes [lo, hi) of the wave (uniform); equals the ordered fold of j_combine over them.
+__device__ inline J wave_range_total(const WaveLines& W, int lo, int hi) {
     J r;
     u32 g = 0;
-    if (!W.lsm) {
-        r.head = unpack_ls(readlane_u32(W.Ih_da, 63), readlane_u32(W.Ih_p, 63), flags_of(W.hb, ~0ull));
+    const u64 m = below(hi) & ~below(lo);
+    const u64 lsm = W.lsm & m, rsm = W.rsm & m, gah = W.gah & m, gat = W.gat & m;
+    const u32 h_lo_da = lo > 0 ? readlane_u32(W.Ih_da, lo - 1) : 0u, h_lo_p = lo > 0 ? readlane_u32(W.Ih_p, lo - 1) : 0u;
+    if (!lsm) {
+        r.head = unpack_ls(readlane_u32(W.Ih_da, hi - 1) - h_lo_da, readlane_u32(W.Ih_p, hi - 1) - h_lo_p,
+                           flags_of(W.hb, m));
         r.tail = ls_empty();
     } else {
-        const int f = ctz(W.lsm), l = top(W.lsm);
-        r.head = unpack_ls(readlane_u32(W.Ih_da, f), readlane_u32(W.Ih_p, f), flags_of(W.hb, below(f + 1)));
+        const int f = ctz(lsm), l = top(lsm);
+        r.head = unpack_ls(readlane_u32(W.Ih_da, f) - h_lo_da, readlane_u32(W.Ih_p, f) - h_lo_p,
+                           flags_of(W.hb, m & below(f + 1)));
         const u32 before_da = l > 0 ? readlane_u32(W.Ix_da, l - 1) : 0u, before_p = l > 0 ? readlane_u32(W.Ix_p, l - 1) : 0u;
-        r.tail = unpack_ls(readlane_u32(W.Ix_da, 63) - before_da, readlane_u32(W.Ix_p, 63) - before_p,
-                           flags_of(W.xb, ~below(l)));
+        r.tail = unpack_ls(readlane_u32(W.Ix_da, hi - 1) - before_da, readlane_u32(W.Ix_p, hi - 1) - before_p,
+                           flags_of(W.xb, m & ~below(l)));
         g |= G_LS;
         const bool c0l = (W.c0m >> l) & 1ull, c1l = (W.c1m >> l) & 1ull;
-        const u64 rs_before = W.rsm & below(l);
+        const u64 rs_before = rsm & below(l);
         bool known;
         if (rs_before) {
             const int r0 = top(rs_before);
-            known = ((W.gat >> r0) & 1ull) || (W.gah & below(l) & ~below(r0 + 1)) != 0;
+            known = ((W.gat >> r0) & 1ull) || (gah & below(l) & ~below(r0 + 1)) != 0;
         } else {
-            known = (W.gah & below(l)) != 0;
+            known = (gah & below(l)) != 0;
             if (c1l) g |= G_C1;
         }
         if (c0l || (c1l && known)) g |= G_C0;
     }
-    if (!W.rsm) {
-        if (W.gah) g |= G_AH | G_AT;
+    if (!rsm) {
+        if (gah) g |= G_AH | G_AT;
     } else {
         g |= G_RS;
-        if (W.gah & below(ctz(W.rsm) + 1)) g |= G_AH;
-        if (W.gat & ~below(top(W.rsm))) g |= G_AT;
+        if (gah & below(ctz(rsm) + 1)) g |= G_AH;
+        if (gat & ~below(top(rsm))) g |= G_AT;
     }
     r.g = g;
     return r;
 }
+__device__ inline J wave_total(const WaveLines& W) { return wave_range_total(W, 0, 64); }
 
 // Field-wise select on values (a select between two members of one struct would otherwise be turned
 // into an indexed load from a stack copy of the struct).
@@ -493,46 +499,43 @@ __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, 
 // ---------------------------------------------------------------------------------------------------
 // k_summary: per-tile forward summary (line statistics at the tile edges, record-level alpha flags).
 // ---------------------------------------------------------------------------------------------------
-constexpr int SUM_TPW = 1;   // consecutive tiles per workgroup (the next one is loaded during the current one)
+// k_summary: per-tile forward summary.  Runs only when k_seed left tiles open (*open_count != 0); the grid is
+// a fixed number of workgroups that stride over the tiles, so that the usual case costs an empty launch.
+constexpr unsigned SUMMARY_GRID = 4096;
 template <bool NORMALIZE>
 __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                                  const u32* __restrict__ rec_lo, u64 R, u64 N,
-                                                 u64 nB, u64 nT, J* __restrict__ SA) {
+                                                 u64 nB, u64 nT, const u32* __restrict__ open_count,
+                                                 J* __restrict__ SA) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ J wsum[NT / 64];
     __shared__ RsShared rs;
-    const u64 t0 = (u64)blockIdx.x * SUM_TPW;
-    TileRegs regs;
-    RsFetch rf;
-    tile_load(bytes, N, t0 * (u64)TILE, regs);
-    rs_fetch(offsets, rec_lo, R, t0, rf);
+    if (*open_count == 0) return;
     stage_tables(uni);
 #pragma unroll 1
-    for (int i = 0; i < SUM_TPW; i++) {
-        const u64 t = t0 + i;
-        if (t >= nT) break;   // uniform
+    for (u64 t = blockIdx.x; t < nT; t += gridDim.x) {
         const u64 tS = t * (u64)TILE;
-        tile_store(regs, sh.bytes);
-        rs_store(rf, offsets, rec_lo, R, N, t, rs);
+        {
+            TileRegs regs;
+            RsFetch rf;
+            tile_load(bytes, N, tS, regs);
+            rs_fetch(offsets, rec_lo, R, t, rf);
+            tile_store(regs, sh.bytes);
+            rs_store(rf, offsets, rec_lo, R, N, t, rs);
+        }
         __syncthreads();
         LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs.w[threadIdx.x], rs.w[threadIdx.x + 1],
                                NORMALIZE);
-        // the next tile's loads are issued after the register-hungry classification
-        if (i + 1 < SUM_TPW && t + 1 < nT) {
-            tile_load(bytes, N, tS + TILE, regs);
-            rs_fetch(offsets, rec_lo, R, t + 1, rf);
-        }
         J j = wave_total(wave_lines(lane_J(L.c, L.d)));
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
-        __syncthreads();
+        __syncthreads();   // also: every lane has finished reading the image and the record starts
         if (threadIdx.x == 0) {
             J acc = wsum[0];
             for (int w = 1; w < NT / 64; w++) acc = j_combine(acc, wsum[w]);
             SA[t] = acc;
         }
-        // the next tile_store may overwrite the image: every lane has finished reading it (barrier above);
-        // wsum is rewritten only after the next barrier
+        __syncthreads();   // wsum is free again
     }
 }
 
@@ -581,33 +584,226 @@ __device__ inline S tile_lookahead(const J* __restrict__ SA, u64 t, u64 nT) {
     return acc;
 }
 
+// Guarded view of a block of the corpus in global memory (zeros outside [0, n)).
+struct GuardBlk {
+    const u8* p;
+    u64 base, n;
+    __device__ u32 operator[](int j) const {
+        long long q = (long long)base + j;
+        return (q >= 0 && (u64)q < n) ? p[q] : 0u;
+    }
+    __device__ u32 word(int k) const {
+        u64 q = base + 4 * (u64)k;
+        if (q + 4 <= n) return *reinterpret_cast<const u32*>(p + q);
+        u32 v = 0;
+        for (int i = 0; i < 4; i++) if (q + i < n) v |= (u32)p[q + i] << (8 * i);
+        return v;
+    }
+};
+
+// k_seed: what enters a tile from the left and from the right, from the bytes next to it.  One wavefront
+// per tile classifies SEED_BACK blocks before the tile and SEED_AHEAD blocks after it, straight from
+// global memory, and folds them; the window is moved outwards while the answer is open, at most
+// SEED_ROUNDS times.  The fold of a window that does not reach back to the record start is as good as
+// the full one once it holds a line start with a letter somewhere before it (then "the record has a
+// letter / a kept line before this line" is true whatever lies further back; normalize mode only asks for
+// a token byte), and the right-hand side is settled by the first line start.  Tiles that stay open are
+// counted; if there are any, k_summary / k_tile_carry redo the seeds of the whole batch from per-tile
+// summaries (long lines, long stretches without a letter).
+constexpr int SEED_TPW = 4;                       // tiles per wavefront
+constexpr int SEED_LPT = 64 / SEED_TPW;           // lanes (= window blocks) per tile
+constexpr int SEED_BACK = 12, SEED_AHEAD = SEED_LPT - SEED_BACK, SEED_ROUNDS = 16;
+// Per tile of a wave: byte images of the two windows (one block of halo on both sides, PadBlk layout) and
+// the record starts of their blocks (one extra word each for "the next block starts a record").
+struct SeedTile {
+    alignas(16) u8 back[(SEED_BACK + 2) * PAD_STRIDE];
+    alignas(16) u8 ahead[(SEED_AHEAD + 2) * PAD_STRIDE];
+    u64 rs_back[SEED_BACK + 1];
+    u64 rs_ahead[SEED_AHEAD + 1];
+};
+struct SeedWave {
+    SeedTile tile[SEED_TPW];
+};
+
+template <bool NORMALIZE>
+__global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, u64 nT,
+                                              u32 force_open, J* __restrict__ seedJ, S* __restrict__ seedS,
+                                              u32* __restrict__ open_count) {
+    __shared__ SeedWave shw[NT / 64];
+    __shared__ UniShared uni;
+    stage_tables(uni);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    SeedWave& sw = shw[threadIdx.x >> 6];
+    const u64 t0 = ((u64)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * SEED_TPW;
+    if (t0 >= nT) return;   // whole waves; no workgroup barrier below
+    const UniTables ut = lds_tables(uni);
+    J P[SEED_TPW];
+    S X[SEED_TPW];
+    bool back_ok[SEED_TPW], ahead_ok[SEED_TPW];
+#pragma unroll
+    for (int k = 0; k < SEED_TPW; k++) {
+        P[k] = j_identity();
+        X[k] = s_identity();
+        const u64 t = t0 + k;
+        back_ok[k] = t == 0 || t >= nT;
+        ahead_ok[k] = (t + 1) * TILE_BLOCKS >= nB;   // also t >= nT
+    }
+    // this lane's place: tile k, window block li of the back or of the ahead window
+    const int my_k = lane / SEED_LPT, l16 = lane % SEED_LPT;
+    const bool is_back = l16 < SEED_BACK;
+    const int li = is_back ? l16 : l16 - SEED_BACK;
+    const long long my_tb0 = (long long)((t0 + my_k) * TILE_BLOCKS);
+    // for the record starts: lane -> region (tile, side), eight lanes per region
+    const int rg_k = lane >> 3, rg_sub = lane & 7;
+#pragma unroll 1
+    for (int round = 0; round < SEED_ROUNDS; round++) {
+        bool any_open = false;
+        u32 open_mask = 0;   // bit 2k: back window of tile k is open, bit 2k+1: ahead window
+#pragma unroll
+        for (int k = 0; k < SEED_TPW; k++) {
+            if (!back_ok[k]) open_mask |= 1u << (2 * k);
+            if (!ahead_ok[k]) open_mask |= 2u << (2 * k);
+        }
+        any_open = open_mask != 0;
+        if (!any_open) break;
+        // ---- stage the open windows: bytes (16-byte chunks, all lanes) ...
+        constexpr int CH_BACK = (SEED_BACK + 2) * 4, CH_TILE = CH_BACK + (SEED_AHEAD + 2) * 4;
+        for (int c = lane; c < SEED_TPW * CH_TILE; c += 64) {
+            const int k = c / CH_TILE, cc = c % CH_TILE;
+            const bool bk = cc < CH_BACK;
+            const int ci = bk ? cc : cc - CH_BACK;
+            if (!((open_mask >> (2 * k + (bk ? 0 : 1))) & 1u)) continue;
+            const long long tb0 = (long long)((t0 + k) * TILE_BLOCKS);
+            const long long first = bk ? tb0 - (long long)SEED_BACK * (round + 1)
+                                       : tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * round;
+            const long long q = (first - 1) * 64 + (long long)ci * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q >= 0) v = load16_guarded(bytes, N, (u64)q);
+            u8* img = bk ? sw.tile[k].back : sw.tile[k].ahead;
+            lds_store16(img + (ci >> 2) * PAD_STRIDE + (ci & 3) * 16, v);
+        }
+        // ... and record starts (cleared, then set by eight lanes per window)
+        for (int i = lane; i < SEED_TPW * (SEED_BACK + 1 + SEED_AHEAD + 1); i += 64) {
+            const int k = i / (SEED_BACK + 1 + SEED_AHEAD + 1), ii = i % (SEED_BACK + 1 + SEED_AHEAD + 1);
+            if (ii <= SEED_BACK) sw.tile[k].rs_back[ii] = 0; else sw.tile[k].rs_ahead[ii - SEED_BACK - 1] = 0;
+        }
+        {
+            static_assert(SEED_TPW * 2 == 8, "eight windows, eight lanes each");
+            const int k = rg_k >> 1;
+            const bool bk = (rg_k & 1) == 0;
+            if ((open_mask >> rg_k) & 1u) {
+                const long long tb0 = (long long)((t0 + k) * TILE_BLOCKS);
+                const long long first = bk ? tb0 - (long long)SEED_BACK * (round + 1)
+                                           : tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * round;
+                const int n = bk ? SEED_BACK : SEED_AHEAD;
+                const long long lo_blk = first < 0 ? 0 : first, hi_blk = first + n;   // starts in [lo_blk*64, (hi_blk+1)*64)
+                if (hi_blk >= 0) {
+                    const u64 T0 = (u64)lo_blk / TILE_BLOCKS, T1 = (u64)hi_blk / TILE_BLOCKS;
+                    const u64 r0 = rec_lo[T0 < nT ? T0 : nT], r1 = rec_lo[T1 + 1 < nT ? T1 + 1 : nT];
+                    const u64 w0 = (u64)lo_blk * 64, w1 = ((u64)hi_blk + 1) * 64;
+                    u64* rs = bk ? sw.tile[k].rs_back : sw.tile[k].rs_ahead;
+                    for (u64 r = r0 + rg_sub; r < r1; r += 8) {
+                        const u64 q = offsets[r];
+                        if (q >= w0 && q < w1 && q < N) {
+                            const u64 d = q - (u64)(first * 64);
+                            atomicOr(reinterpret_cast<unsigned long long*>(&rs[d >> 6]), 1ull << (d & 63));
+                        }
+                    }
+                }
+            }
+        }
+        __threadfence_block();   // the wave's own LDS writes are complete before any lane reads them
+        // ---- classify this lane's window block
+        const long long first = is_back ? my_tb0 - (long long)SEED_BACK * (round + 1)
+                                        : my_tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * round;
+        const long long wb = first + li;
+        const bool live = wb >= 0 && (u64)wb < nB && ((open_mask >> (2 * my_k + (is_back ? 0 : 1))) & 1u);
+        J j = j_identity();
+        if (live) {
+            const u64 q = (u64)wb * 64;
+            const SeedTile& st = sw.tile[my_k];
+            const PadBlk blk = {(is_back ? st.back : st.ahead) + (li + 1) * PAD_STRIDE};
+            const u64* rsw = is_back ? st.rs_back : st.rs_ahead;
+            const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
+            const u64 V = below(nvalid);
+            const u64 RS = rsw[li] & V;
+            const bool nrs = (rsw[li + 1] & 1ull) != 0;
+            Cls c;
+            Derived d;
+            if (NORMALIZE) {
+                Cls z = {classify_ws_fast(blk, nvalid), 0, 0, 0, 0, 0, 0};
+                c = normalize_cls(z, V);
+                d = derive(c, V, RS, false, false);
+            } else {
+                c = classify_block_fast(blk, nvalid, ut);
+                const bool has_next = q + 64 < N;
+                const bool next_nl = has_next && blk[64] == '\n' && !nrs;
+                const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
+                d = derive(c, V, RS, next_nl, pt);
+            }
+            j = lane_J(c, d);
+        }
+        const WaveLines W = wave_lines(j);
+#pragma unroll
+        for (int k = 0; k < SEED_TPW; k++) {
+            const long long tb0 = (long long)((t0 + k) * TILE_BLOCKS);
+            if (!back_ok[k]) {
+                P[k] = j_combine(wave_range_total(W, k * SEED_LPT, k * SEED_LPT + SEED_BACK), P[k]);
+                const bool settled = NORMALIZE ? (P[k].g & (G_RS | G_AH)) != 0
+                                               : (P[k].g & G_RS) != 0 || ((P[k].g & G_LS) && (P[k].g & G_C0));
+                back_ok[k] = settled || tb0 - (long long)SEED_BACK * (round + 1) <= 0;   // or the corpus starts here
+            }
+            if (!ahead_ok[k]) {
+                X[k] = s_combine(X[k], s_from_J(wave_range_total(W, k * SEED_LPT + SEED_BACK, (k + 1) * SEED_LPT)));
+                ahead_ok[k] = X[k].has_ls != 0 ||
+                              (u64)(tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * (round + 1)) >= nB;
+            }
+        }
+        __threadfence_block();   // every lane has read the images before the next round overwrites them
+    }
+    bool open = force_open != 0;
+#pragma unroll
+    for (int k = 0; k < SEED_TPW; k++) {
+        if (t0 + k < nT) {
+            if (lane == 0) { seedJ[t0 + k] = P[k]; seedS[t0 + k] = X[k]; }
+            open = open || !(back_ok[k] && ahead_ok[k]);
+        }
+    }
+    if (open && lane == 0) *open_count = 1u;   // same value from every writer
+}
+
 // k_tile_carry: what enters tile t from the left (fold of the summaries back to the start of the
 // record that covers the tile's first byte) and from the right (rest of the line that leaves the tile).
 // Usually the neighbouring tiles settle both (a record start within the previous few tiles, a line start
 // in the next one): one thread per tile looks at most TC_NEAR tiles each way and lists the tiles that
 // need a longer walk; those are then folded by one wavefront each, 64 summaries at a time.
 constexpr int TC_NEAR = 4;
-__global__ void k_tile_carry_near(const J* __restrict__ SA, u64 nT, J* __restrict__ seedJ, S* __restrict__ seedS,
+__global__ void k_tile_carry_near(const J* __restrict__ SA, u64 nT, const u32* __restrict__ open_count,
+                                  J* __restrict__ seedJ, S* __restrict__ seedS,
                                   u32* __restrict__ far_list, u32* __restrict__ far_count) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nT) return;
-    J P = j_identity();
-    bool ok = false;
-    for (int step = 1; step <= TC_NEAR; step++) {
-        if (t < (u64)step) { ok = true; break; }
-        const J v = SA[t - step];
-        P = j_combine(v, P);
-        if (v.g & G_RS) { ok = true; break; }
+    if (*open_count == 0) return;   // k_seed has settled every tile
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < nT; t += nthreads) {
+        J P = j_identity();
+        bool ok = false;
+        for (int step = 1; step <= TC_NEAR; step++) {
+            if (t < (u64)step) { ok = true; break; }
+            const J v = SA[t - step];
+            P = j_combine(v, P);
+            if (v.g & G_RS) { ok = true; break; }
+        }
+        S X = s_identity();
+        bool ok2 = false;
+        for (int step = 1; step <= TC_NEAR; step++) {
+            if (t + step >= nT) { ok2 = true; break; }
+            X = s_combine(X, s_from_J(SA[t + step]));
+            if (X.has_ls) { ok2 = true; break; }
+        }
+        if (ok && ok2) { seedJ[t] = P; seedS[t] = X; }
+        else far_list[atomicAdd(far_count, 1u)] = (u32)t;
     }
-    S X = s_identity();
-    bool ok2 = false;
-    for (int step = 1; step <= TC_NEAR; step++) {
-        if (t + step >= nT) { ok2 = true; break; }
-        X = s_combine(X, s_from_J(SA[t + step]));
-        if (X.has_ls) { ok2 = true; break; }
-    }
-    if (ok && ok2) { seedJ[t] = P; seedS[t] = X; }
-    else far_list[atomicAdd(far_count, 1u)] = (u32)t;
 }
 
 __global__ __launch_bounds__(NT) void k_tile_carry(const J* __restrict__ SA, u64 nT, J* __restrict__ seedJ,
@@ -1048,23 +1244,6 @@ __device__ inline void plan_or(Plan* plan, u64 word, u64 c, u64 tok, u64 psp, u6
     if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PSP), psp);
     if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PNL), pnl);
 }
-
-// Guarded view of a block of the corpus in global memory (zeros outside [0, n)).
-struct GuardBlk {
-    const u8* p;
-    u64 base, n;
-    __device__ u32 operator[](int j) const {
-        long long q = (long long)base + j;
-        return (q >= 0 && (u64)q < n) ? p[q] : 0u;
-    }
-    __device__ u32 word(int k) const {
-        u64 q = base + 4 * (u64)k;
-        if (q + 4 <= n) return *reinterpret_cast<const u32*>(p + q);
-        u32 v = 0;
-        for (int i = 0; i < 4; i++) if (q + i < n) v |= (u32)p[q + i] << (8 * i);
-        return v;
-    }
-};
 
 // Serial solver for one listed line (any length): lane-local walk over the bytes, results OR-ed into
 // the plan with atomics.
@@ -1791,6 +1970,9 @@ struct trp_ctx {
     u64 last_R = 0;
     bool have_last = false;
     trp_ctx* aux = nullptr;             // second set of buffers + stream for the pipelined host path
+    // Test aid: TRIPLETS_AMD_FORCE_SUMMARY=1 in the environment when the context is created makes every
+    // batch take the per-tile-summary path for the tile seeds (normally only batches that k_seed cannot settle).
+    u32 force_summary = 0;
     // batch in flight between submit_device and collect_device
     struct Pending {
         bool active = false;
@@ -1892,10 +2074,11 @@ int trp_create(int device, trp_ctx** out) {
     if (device < 0 || device >= n) return fail(TRP_E_ARG, "device ordinal out of range");
     HIPCHK(hipSetDevice(device));
     trp_ctx* c = new trp_ctx();
+    { const char* e2 = getenv("TRIPLETS_AMD_FORCE_SUMMARY"); c->force_summary = (e2 && atoi(e2)) ? 1u : 0u; }
     c->device = device;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(TRP_E_HIP, "hipStreamCreate failed"); }
-    e = hipHostMalloc((void**)&c->h_totals, 8 * sizeof(u64), hipHostMallocDefault);
+    e = hipHostMalloc((void**)&c->h_totals, 16 * sizeof(u64), hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(TRP_E_HIP, "hipHostMalloc failed"); }
     *out = c;
     return TRP_OK;
@@ -1986,7 +2169,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if ((rc = c->tok_start.ensure(tok_cap * sizeof(u32)))) return rc;
     if ((rc = c->tok_len.ensure(tok_cap * sizeof(u32)))) return rc;
     if ((rc = c->chunks.ensure(chunk_cap * sizeof(ChunkDesc)))) return rc;
-    if ((rc = c->totals.ensure(8 * sizeof(u64)))) return rc;
+    if ((rc = c->totals.ensure(16 * sizeof(u64)))) return rc;
     if (!pass) {
         if ((rc = c->SA.ensure((nT + 1) * sizeof(J)))) return rc;
         if ((rc = c->plan.ensure((nB + 1) * sizeof(Plan)))) return rc;
@@ -2005,7 +2188,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     Plan* plan = c->plan.as<Plan>();
     J* SA = c->SA.as<J>();
     c->events.clear();
-    HIPCHK(hipMemsetAsync(totals, 0, 8 * sizeof(u64), st));
+    HIPCHK(hipMemsetAsync(totals, 0, 16 * sizeof(u64), st));
 
     {
         Prof pr(c, "k_rec_lo");
@@ -2013,15 +2196,25 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     }
     if (nT) {
         if (!pass) {
+            u32* open_count = reinterpret_cast<u32*>(totals + 8);   // zeroed with the totals
+            { Prof pr(c, "k_seed");
+              const dim3 grid((unsigned)((nT + SEED_TPW * (NT / 64) - 1) / (SEED_TPW * (NT / 64))));
+              if (dc.normalize)
+                  hipLaunchKernelGGL(k_seed<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
+                                     c->seedJ.as<J>(), c->seedS.as<S>(), open_count);
+              else
+                  hipLaunchKernelGGL(k_seed<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
+                                     c->seedJ.as<J>(), c->seedS.as<S>(), open_count); }
+            // the next three return at once unless k_seed left tiles open
             { Prof pr(c, "k_summary");
-              const dim3 grid((unsigned)((nT + SUM_TPW - 1) / SUM_TPW));
-              if (dc.normalize) hipLaunchKernelGGL(k_summary<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, SA);
-              else hipLaunchKernelGGL(k_summary<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, SA); }
+              const dim3 grid((unsigned)std::min<u64>(nT, SUMMARY_GRID));
+              if (dc.normalize) hipLaunchKernelGGL(k_summary<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA);
+              else hipLaunchKernelGGL(k_summary<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA); }
             { Prof pr(c, "k_tile_carry");
               u32* far_count = reinterpret_cast<u32*>(totals + 7);   // zeroed with the totals
-              hipLaunchKernelGGL(k_tile_carry_near, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, SA, nT,
-                                 c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count);
-              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 4096)), dim3(NT), 0, st,
+              hipLaunchKernelGGL(k_tile_carry_near, dim3((unsigned)std::min<u64>((nT + 255) / 256, 1024)), dim3(256), 0, st, SA, nT,
+                                 open_count, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count);
+              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 1024)), dim3(NT), 0, st,
                                  SA, nT, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count); }
             { Prof pr(c, "k_plan");
               if (dc.normalize)

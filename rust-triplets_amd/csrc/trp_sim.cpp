@@ -161,17 +161,44 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
             SA[t] = acc;
         }
         for (u64 t = 0; t < nT; t++) {
-            // look-back to the start of the record that covers the first byte of the tile
+            // As on the device (k_seed): first try to settle both sides from windows of blocks next to the
+            // tile (48 before, 16 after, moved outwards up to 8 times); a window that does not reach the
+            // record start is enough once it holds a line start with a letter before it.
             J P = j_identity();
-            for (u64 u = t; u-- > 0;) {
-                P = j_combine(SA[u], P);
-                if (P.g & G_RS) break;
-            }
-            // look-ahead to the next line start
             S X = s_identity();
-            for (u64 u = t + 1; u < nT; u++) {
-                X = s_combine(X, s_from_J(SA[u]));
-                if (X.has_ls) break;
+            const long long tb0 = (long long)(t * tile_blocks), tb1 = tb0 + (long long)tile_blocks;
+            bool back_ok = t == 0, ahead_ok = (u64)tb1 >= nB;
+            for (int round = 0; round < 8 && !(back_ok && ahead_ok); round++) {
+                if (!back_ok) {
+                    long long lo = tb0 - 48LL * (round + 1), hi = tb0 - 48LL * round;
+                    J Wj = j_identity();
+                    for (long long b = lo < 0 ? 0 : lo; b < hi; b++) Wj = j_combine(Wj, jl[b]);
+                    P = j_combine(Wj, P);
+                    bool settled = cfg.normalize ? (P.g & (G_RS | G_AH)) != 0
+                                                 : (P.g & G_RS) != 0 || ((P.g & G_LS) && (P.g & G_C0));
+                    back_ok = settled || lo <= 0;
+                }
+                if (!ahead_ok) {
+                    long long lo = tb1 + 16LL * round, hi = tb1 + 16LL * (round + 1);
+                    J Wj = j_identity();
+                    for (long long b = lo; b < hi && (u64)b < nB; b++) Wj = j_combine(Wj, jl[b]);
+                    X = s_combine(X, s_from_J(Wj));
+                    ahead_ok = X.has_ls != 0 || (u64)hi >= nB;
+                }
+            }
+            if (!(back_ok && ahead_ok)) {
+                // look-back to the start of the record that covers the first byte of the tile
+                P = j_identity();
+                for (u64 u = t; u-- > 0;) {
+                    P = j_combine(SA[u], P);
+                    if (P.g & G_RS) break;
+                }
+                // look-ahead to the next line start
+                X = s_identity();
+                for (u64 u = t + 1; u < nT; u++) {
+                    X = s_combine(X, s_from_J(SA[u]));
+                    if (X.has_ls) break;
+                }
             }
             u64 b0 = t * tile_blocks, b1 = (t + 1) * tile_blocks < nB ? (t + 1) * tile_blocks : nB;
             std::vector<S> suf(b1 - b0);
