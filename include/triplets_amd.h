@@ -122,7 +122,8 @@ void trp_trim_host_pool(void);
 /* Same path with the batch already resident in GPU memory (16-byte aligned `d_bytes`, device
  * `d_offsets`).  The result arrays are device pointers into buffers owned by the context; they stay
  * valid until the next call on this context.  The call returns after the kernels have completed
- * (the totals in `out` are read back). */
+ * (the totals in `out` are read back).  The kernels run on the context's own stream (trp_stream):
+ * whatever produces `d_bytes` / `d_offsets` on another stream must have completed before the call. */
 int trp_preprocess_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                 uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
                                 trp_result* out);

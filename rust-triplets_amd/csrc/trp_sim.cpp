@@ -162,15 +162,15 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
         }
         for (u64 t = 0; t < nT; t++) {
             // As on the device (k_seed): first try to settle both sides from windows of blocks next to the
-            // tile (48 before, 16 after, moved outwards up to 8 times); a window that does not reach the
+            // tile (12 before, 4 after, moved outwards up to 16 times); a window that does not reach the
             // record start is enough once it holds a line start with a letter before it.
             J P = j_identity();
             S X = s_identity();
             const long long tb0 = (long long)(t * tile_blocks), tb1 = tb0 + (long long)tile_blocks;
             bool back_ok = t == 0, ahead_ok = (u64)tb1 >= nB;
-            for (int round = 0; round < 8 && !(back_ok && ahead_ok); round++) {
+            for (int round = 0; round < 16 && !(back_ok && ahead_ok); round++) {
                 if (!back_ok) {
-                    long long lo = tb0 - 48LL * (round + 1), hi = tb0 - 48LL * round;
+                    long long lo = tb0 - 12LL * (round + 1), hi = tb0 - 12LL * round;
                     J Wj = j_identity();
                     for (long long b = lo < 0 ? 0 : lo; b < hi; b++) Wj = j_combine(Wj, jl[b]);
                     P = j_combine(Wj, P);
@@ -179,7 +179,7 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                     back_ok = settled || lo <= 0;
                 }
                 if (!ahead_ok) {
-                    long long lo = tb1 + 16LL * round, hi = tb1 + 16LL * (round + 1);
+                    long long lo = tb1 + 4LL * round, hi = tb1 + 4LL * (round + 1);
                     J Wj = j_identity();
                     for (long long b = lo; b < hi && (u64)b < nB; b++) Wj = j_combine(Wj, jl[b]);
                     X = s_combine(X, s_from_J(Wj));

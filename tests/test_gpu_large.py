@@ -67,6 +67,7 @@ def check_batch(name, data, offs, overlaps, sample_bytes=6_000_000):
     import torch
     d_bytes = torch.from_numpy(data).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
     dev = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
     res = dev.to_host()
 
@@ -112,6 +113,7 @@ def check_batch(name, data, offs, overlaps, sample_bytes=6_000_000):
     # ---- the token table equals split_whitespace of the denoised text (pass-through path) --------------
     d_den = torch.from_numpy(res.denoised).cuda()
     d_doff = torch.from_numpy(res.denoised_offsets.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
     thru = ctx.preprocess_batch_device(d_den.data_ptr(), d_doff.data_ptr(), R, res.n_denoised,
                                        T.DenoiserConfig(False, 0.35, True), st)
     assert int(thru.n_tokens) == res.n_tokens
@@ -128,6 +130,7 @@ def check_batch(name, data, offs, overlaps, sample_bytes=6_000_000):
         sub_offs = torch.from_numpy((offs[r0:r1 + 1] - np.uint64(b0)).astype(np.int64)).cuda()
         # the device variant wants a 16-byte aligned text pointer: copy the half to a fresh buffer
         sub = d_bytes[b0:b1].clone()
+        torch.cuda.synchronize()   # clone() is asynchronous on torch's stream
         h = ctx.preprocess_batch_device(sub.data_ptr(), sub_offs.data_ptr(), r1 - r0, b1 - b0, den, st)
         parts.append(h.to_host())
     assert_same(res, T.concat_results(parts), None, name + " halves")
@@ -172,6 +175,7 @@ def test_config_c_full_size_four_gigabytes():
     ctx = T.Context(0)
     d_bytes = torch.from_numpy(data).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
     dev = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, den, st)
     doff = dev.fetch("denoised_offsets", R + 1, np.uint64)
     toff = dev.fetch("tok_offsets", R + 1, np.uint64)

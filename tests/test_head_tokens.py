@@ -34,6 +34,7 @@ def test_head_tokens_text(enabled):
     ctx = T.Context(0)
     d_bytes = torch.from_numpy(data).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
     dev = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), len(recs), len(data),
                                       T.DenoiserConfig(enabled, 0.35, True), T.ChunkingStrategy())
     R = len(recs)

@@ -107,6 +107,7 @@ def test_gpu_large_batch_properties():
     ctx = T.Context(0)
     d_bytes = torch.from_numpy(data).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()   # the library runs on its own stream: inputs must be complete
     st = T.ChunkingStrategy()
     thru = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), R, N, T.DenoiserConfig(False, 0.35, True), st)
     t_len = thru.fetch("tok_len", thru.n_tokens, np.uint32)
