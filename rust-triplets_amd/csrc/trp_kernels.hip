@@ -648,7 +648,8 @@ __global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const
         X[k] = s_identity();
         const u64 t = t0 + k;
         back_ok[k] = t == 0 || t >= nT;
-        ahead_ok[k] = (t + 1) * TILE_BLOCKS >= nB;   // also t >= nT
+        // normalize mode has no lines: nothing of what follows the tile matters to it
+        ahead_ok[k] = NORMALIZE || (t + 1) * TILE_BLOCKS >= nB;   // also t >= nT
     }
     // this lane's place: tile k, window block li of the back or of the ahead window
     const int my_k = lane / SEED_LPT, l16 = lane % SEED_LPT;

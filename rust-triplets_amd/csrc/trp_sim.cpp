@@ -167,7 +167,7 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
             J P = j_identity();
             S X = s_identity();
             const long long tb0 = (long long)(t * tile_blocks), tb1 = tb0 + (long long)tile_blocks;
-            bool back_ok = t == 0, ahead_ok = (u64)tb1 >= nB;
+            bool back_ok = t == 0, ahead_ok = cfg.normalize || (u64)tb1 >= nB;
             for (int round = 0; round < 16 && !(back_ok && ahead_ok); round++) {
                 if (!back_ok) {
                     long long lo = tb0 - 12LL * (round + 1), hi = tb0 - 12LL * round;
