@@ -1645,7 +1645,6 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
         u32 o = ex.nb - out0 + shift;
         u64 Cm = pl.C;
         u64 brk = Cm & (PFX | ~(Cm << 1));
-        const u32 lrot = threadIdx.x & 15;
         while (brk) {
             int a0 = ctz(brk);
             brk &= brk - 1;
@@ -1659,14 +1658,25 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
             if (head > len) head = len;
             for (u32 i = 0; i < head; i++) dst[i] = src[i];
             const u32 nd = (len - head) >> 2;
-            const u32 rot = (lrot * nd) >> 4;
-            // destination dwords are aligned; the source is read as aligned dword pairs and shifted in
-            // registers (LDS accesses that straddle a dword stall the whole LDS pipeline)
+            // destination dwords are aligned; the source is read as aligned dwords and shifted in
+            // registers (LDS accesses that straddle a dword stall the whole LDS pipeline).  Four dwords
+            // at a time (five source dwords), the rest one by one.
             const u32 sa = (u32)(a0 + head) & 3u;            // the block itself is dword aligned
             const u8* sbase = src + head - sa;
-            for (u32 q = 0; q < nd; q++) {
-                u32 k = q + rot;
-                if (k >= nd) k -= nd;
+            const u32 ng = nd >> 2;
+            const u32 grot = ((threadIdx.x & 3u) * ng) >> 2;
+            for (u32 q = 0; q < ng; q++) {
+                u32 k = q + grot;
+                if (k >= ng) k -= ng;
+                const u32* sp = reinterpret_cast<const u32*>(sbase + 16 * k);
+                const u32 w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
+                u32* dp = reinterpret_cast<u32*>(dst + head + 16 * k);
+                dp[0] = __builtin_amdgcn_alignbyte(w1, w0, sa);
+                dp[1] = __builtin_amdgcn_alignbyte(w2, w1, sa);
+                dp[2] = __builtin_amdgcn_alignbyte(w3, w2, sa);
+                dp[3] = __builtin_amdgcn_alignbyte(w4, w3, sa);
+            }
+            for (u32 k = ng * 4; k < nd; k++) {
                 const Pair32 w = *reinterpret_cast<const Pair32*>(sbase + 4 * k);
                 *reinterpret_cast<u32*>(dst + head + 4 * k) = __builtin_amdgcn_alignbyte(w.hi, w.lo, sa);
             }
