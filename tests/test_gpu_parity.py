@@ -246,3 +246,33 @@ def test_scripts_and_rule_boundaries(T, ctx, seed):
     for cfg in ((True, 0.35, True, 12, (3,), 4), (True, 0.8, False, 1024, (64,), 512), (False, 0.35, True, 12, (3,), 4)):
         exp, got = _run(T, ctx, recs, cfg)
         assert_same(exp, got, recs, "scripts%d" % seed)
+
+
+def test_tile_carries_from_windows_and_from_summaries(T, ctx):
+    """Batches whose tile carries are settled by the windows next to each tile, batches that need the
+    per-tile summaries (long letterless stretches, lines longer than the windows reach), and the same
+    batches with the summary path forced: all equal to the oracle."""
+    plain = textgen.corpus(31, 600)
+    letterless = ("12 34 56 78\n" * 20000 + "word at last\n" + "9 9 9\n" * 3000).encode()       # ~300 KB without a letter
+    long_line = (" ".join("w%d" % i for i in range(12000)) + "\nnext line\n").encode()          # one 70 KB line
+    long_digits = ("7 " * 40000 + "x\n").encode()                                               # digit-heavy 80 KB line
+    spaces = b" " * 150000 + b"x" + b" " * 150000 + b"y"
+    batches = [plain, plain[:50] + [letterless] + plain[50:100], [long_line] + plain[:30] + [long_digits],
+               [spaces, b"", spaces], plain[:10] + [letterless, long_line, spaces] + plain[10:20]]
+    os.environ["TRIPLETS_AMD_FORCE_SUMMARY"] = "1"
+    try:
+        forced = T.Context(0)
+    finally:
+        del os.environ["TRIPLETS_AMD_FORCE_SUMMARY"]
+    try:
+        for i, recs in enumerate(batches):
+            for cfg in ((True, 0.35, True, 1024, (64,), 512), (True, 0.9, False, 16, (3,), 4)):
+                exp, got = _run(T, ctx, recs, cfg)
+                assert_same(exp, got, recs, "windows %d" % i)
+                exp2, got2 = _run(T, forced, recs, cfg)
+                assert_same(exp2, got2, recs, "summaries %d" % i)
+            data, offs = O.pack(recs)
+            a, b = ctx.normalize_batch(data, offs), forced.normalize_batch(data, offs)
+            assert a.denoised.tobytes() == b.denoised.tobytes() and np.array_equal(a.tok_offsets, b.tok_offsets)
+    finally:
+        forced.close()
