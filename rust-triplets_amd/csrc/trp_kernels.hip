@@ -822,8 +822,7 @@ __global__ __launch_bounds__(NT) void k_tile_carry(const J* __restrict__ SA, u64
 
 // ---- digit-heavy lines solved inside the tile (one wavefront per line) ---------------------------
 constexpr u32 G3_LCAP = 1024;   // lines per tile that can be listed in LDS
-constexpr u32 G3_MAXW = 4;      // a line may touch at most this many 64-byte blocks ...
-constexpr u32 G3_MAXT = 64;     // ... and hold at most this many tokens; longer lines go to k_gate3_solve
+constexpr u32 G3_MAXW = 4;      // a line may touch at most this many 64-byte blocks; longer ones are walked serially
 
 
 // Per-block masks of the tile, kept in the LDS region of the (no longer needed) byte image.
@@ -832,154 +831,11 @@ struct G3Masks {
     u64 *G, *gPSP, *gPNL;              // outputs: kept token bytes, ' ' / '\n' separators
 };
 
-// Solves one digit-heavy line (gate 3, reference strip_digit_tokens, denoiser_preprocessor.rs:70-140) with
-// the 64 lanes of a wave.  Returns false when the line does not fit (left to the serial solver).
-// The mask arrays are indexed by block number within a view of n_words blocks; s is the position of
-// the line's first byte in the view and corpus_end the position where the corpus ends (or ~0 when that
-// is outside the view).
-//   1. token starts of the line's (at most four) blocks; the lane whose index is the bit position of a
-//      start counts the digits and letters of that token and files them under the token's number;
-//   2. in token space (bit t = token t) everything is wave-uniform mask algebra: the seed set is the
-//      tokens with a letter, wave k the not yet kept neighbours of the kept set, sums are popcounts over
-//      the ballots of the bit planes of the per-token counts;
-//   3. back in byte space the kept tokens are the runs of token bytes whose start bit is kept
-//      (runs & ~(runs + kept_starts), with the carry passed from block to block).
-__device__ inline bool g3_wave_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
-                                     float max_ratio, u32* tb) {
-    const int lane = threadIdx.x & 63;
-    const u32 w0 = s >> 6;
-    // end of the line: the next line start, or the end of the corpus
-    u32 e = 0xFFFFFFFFu;
-    for (u32 w = w0; w <= w0 + G3_MAXW && w < n_words; w++) {
-        u64 m = a.ls[w];
-        if (w == w0) m &= ~below((int)(s & 63u) + 1);
-        if (m) { e = w * 64u + (u32)ctz(m); break; }
-    }
-    if (e == 0xFFFFFFFFu) {
-        if (corpus_end != 0xFFFFFFFFu && corpus_end <= (w0 + G3_MAXW) * 64u) e = corpus_end;
-        else return false;
-    }
-    const u32 w1 = (e - 1u) >> 6;
-    if (w1 - w0 >= G3_MAXW) return false;
-    const u32 nw = w1 - w0 + 1u;
-    u64 X[G3_MAXW], DG[G3_MAXW], AL[G3_MAXW], TS[G3_MAXW];
-    u32 pre[G3_MAXW + 1];
-    pre[0] = 0;
-    u64 carry = 0;
-#pragma unroll
-    for (u32 j = 0; j < G3_MAXW; j++) {
-        X[j] = DG[j] = AL[j] = TS[j] = 0;
-        if (j < nw) {
-            const u32 w = w0 + j;
-            u64 range = ~0ull;
-            if (w == w0) range &= ~below((int)(s & 63u));
-            if (w == w1 && (e & 63u)) range &= below((int)(e & 63u));
-            const u64 sep = a.ws[w] | (table ? a.pipe[w] : 0ull);
-            X[j] = ~sep & range;
-            DG[j] = a.dig[w] & range;
-            AL[j] = a.alp[w] & range;
-            TS[j] = X[j] & ~((X[j] << 1) | carry);
-            carry = X[j] >> 63;
-        }
-        pre[j + 1] = pre[j] + (u32)popc(TS[j]);
-    }
-    const u32 nt = pre[G3_MAXW];
-    if (nt == 0 || nt > G3_MAXT) return false;
-    // 1. per-token digit / letter counts, filed by token number
-    u32 my_t[G3_MAXW];
-#pragma unroll
-    for (u32 j = 0; j < G3_MAXW; j++) {
-        my_t[j] = 0xFFFFFFFFu;
-        if ((TS[j] >> lane) & 1ull) {
-            const u32 t = pre[j] + (u32)popc(TS[j] & below(lane));
-            my_t[j] = t;
-            const u64 from = ~below(lane);
-            const u64 stop = ~X[j] & from;
-            u32 dig, alp;
-            if (stop) {
-                const u64 r = from & below(ctz(stop));
-                dig = popc(DG[j] & r);
-                alp = popc(AL[j] & r);
-            } else {
-                dig = popc(DG[j] & from);
-                alp = popc(AL[j] & from);
-                bool done = false;
-#pragma unroll
-                for (u32 j2 = j + 1; j2 < G3_MAXW; j2++) {
-                    if (!done && j2 < nw) {
-                        const u64 stop2 = ~X[j2];
-                        const u64 r2 = stop2 ? below(ctz(stop2)) : ~0ull;
-                        dig += popc(DG[j2] & r2);
-                        alp += popc(AL[j2] & r2);
-                        done = stop2 != 0;
-                    }
-                }
-            }
-            tb[t] = dig | (alp << 16);
-        }
-    }
-    __threadfence_block();
-    const u32 mine = (u32)lane < nt ? tb[lane] : 0u;
-    const u32 dig = mine & 0xFFFFu, alp = mine >> 16;
-    // 2. token space
-    const u64 valid = below((int)nt);
-    const u64 A = __ballot(alp > 0);
-    u64 pd[9], pa[9];   // a token has at most 256 bytes
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        pd[k] = __ballot((dig >> k) & 1u);
-        pa[k] = __ballot((alp >> k) & 1u);
-    }
-    u64 d0 = 0, a0 = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        d0 += (u64)popc(pd[k] & A) << k;
-        a0 += (u64)popc(pa[k] & A) << k;
-    }
-    u64 kept = A;
-    while (true) {
-        const u64 next = (kept | (kept << 1) | (kept >> 1)) & valid;
-        const u64 wave_k = next & ~kept;
-        if (!wave_k) break;
-        u64 wd = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) wd += (u64)popc(pd[k] & wave_k) << k;
-        if (ratio_exceeds64(d0 + wd, a0, max_ratio)) break;
-        d0 += wd;
-        kept = next;
-    }
-    // 3. byte space: kept starts per block, then the runs they start
-    u64 first_pending = 1;   // the first kept token gets the line-break flag, the others a space
-    u64 cin = 0;
-#pragma unroll
-    for (u32 j = 0; j < G3_MAXW; j++) {
-        if (j < nw) {
-            const bool k_here = my_t[j] != 0xFFFFFFFFu && ((kept >> my_t[j]) & 1ull);
-            const u64 ks = __ballot(k_here);   // kept token starts of block j
-            const u64 t1 = X[j] + ks, sum = t1 + cin;
-            const u64 g = X[j] & ~sum;
-            cin = (t1 < ks || sum < t1) ? 1ull : 0ull;   // carry out: a kept run reaches the next block
-            u64 psp = ks, pnl = 0;
-            if (first_pending && ks) {
-                const u64 low = ks & (0ull - ks);
-                psp = ks & ~low;
-                if (rab) pnl = low;
-                first_pending = 0;
-            }
-            if (lane == 0) {
-                if (g) atomicOr(reinterpret_cast<unsigned long long*>(&a.G[w0 + j]), g);
-                if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPSP[w0 + j]), psp);
-                if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&a.gPNL[w0 + j]), pnl);
-            }
-        }
-    }
-    return true;
-}
-
-// The same problem solved by a single lane (one line per lane, 64 lines per wave at a time) with
-// g3_bits_solve: no walk over the tokens, no limit on their number.  Used inside k_plan where a tile
-// holds dozens of short digit-heavy lines.  Returns false when the line does not fit (more than
-// G3_WORDS blocks).
+// One digit-heavy line (gate 3, reference strip_digit_tokens, denoiser_preprocessor.rs:70-140) solved by a
+// single lane (64 lines per wave at a time) with g3_bits_solve: no walk over the tokens, no limit on their
+// number.  The mask arrays are indexed by block number within a view of n_words blocks; s is the position
+// of the line's first byte in the view and corpus_end the position where the corpus ends (or ~0 when that
+// is outside the view).  Returns false when the line does not fit (more than G3_WORDS blocks).
 static_assert(G3_WORDS == (int)G3_MAXW, "the lane solver and the wave solver take the same lines");
 __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
                                      float max_ratio) {
@@ -1042,7 +898,6 @@ struct PlanShared {
     u64 tokc[TILE_BLOCKS];
     u64 marks[TILE_BLOCKS];
     uint16_t list[G3_LCAP];
-    u32 tok[NT / 64][G3_MAXT];
     u32 scan32[NT / 64];
     u32 nlist;
     u64 g3base;
@@ -1285,37 +1140,49 @@ __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* 
             });
 }
 
-// Lines that k_plan could not solve inside a tile (they cross a tile edge or are too long): one
-// wavefront per listed line.  Lines of up to G3_MAXW blocks are re-classified from global memory by
-// five lanes and go through the same wave solver; the rest is walked serially by lane 0.
+// Lines that k_plan could not solve inside a tile (they cross a tile edge or are too long): twelve listed
+// lines per wavefront (one wavefront per workgroup).  Lane 5 * l + j re-classifies block j of line l's first
+// five blocks from global memory into the line's mask arrays in LDS; lane 5 * l then runs the same solver
+// as k_plan, or walks the line serially when it has more than G3_MAXW blocks.
 constexpr u32 G3_VIEW = G3_MAXW + 1;
-__global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes,
+constexpr int G3S_LINES = 64 / G3_VIEW;             // lines per wavefront
+constexpr int G3S_STRIDE = 8 * (G3_VIEW + 1) + 1;   // u64 per line; odd, so that the lines spread over the banks
+__global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes,
                                                      const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
                                                      Plan* plan, const u64* __restrict__ list,
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
                                                      u32* tile_toks, u64* __restrict__ totals) {
-    __shared__ u64 masks[NT / 64][8][G3_VIEW + 1];
-    __shared__ u32 tok[NT / 64][G3_MAXT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ u64 masks[G3S_LINES * G3S_STRIDE];
+    const int lane = threadIdx.x;
     u64 n = *mark_total;
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[4] = n; totals[5] = n > cap ? 1 : 0; }
     if (n > cap) n = cap;
-    const u64 nwaves = (u64)gridDim.x * (NT / 64);
-    for (u64 i = (u64)blockIdx.x * (NT / 64) + wave; i < n; i += nwaves) {
-        const u64 ent = list[i];
-        const u64 p = ent & 0xFFFFFFFFull;
-        const bool table = (ent >> 32) & 1, rab = (ent >> 33) & 1;
+    const int l = lane / (int)G3_VIEW, j = lane % (int)G3_VIEW;   // line of the group, block of its view
+    u64* m = masks + (l < G3S_LINES ? l : 0) * G3S_STRIDE;        // eight arrays of G3_VIEW + 1 words
+    const G3Masks gm = {m, m + (G3_VIEW + 1), m + 2 * (G3_VIEW + 1), m + 3 * (G3_VIEW + 1), m + 4 * (G3_VIEW + 1),
+                        m + 5 * (G3_VIEW + 1), m + 6 * (G3_VIEW + 1), m + 7 * (G3_VIEW + 1)};
+    const UniTables ut = dev_tables();
+    for (u64 i0 = (u64)blockIdx.x * G3S_LINES; i0 < n; i0 += (u64)gridDim.x * G3S_LINES) {   // uniform
+        const u64 i = i0 + (u64)l;
+        const bool have = l < G3S_LINES && i < n;
+        u64 p = 0;
+        bool table = false, rab = false;
+        if (have) {
+            const u64 ent = list[i];
+            p = ent & 0xFFFFFFFFull;
+            table = (ent >> 32) & 1;
+            rab = (ent >> 33) & 1;
+        }
         const u64 w0 = p >> 6;
-        u64(*m)[G3_VIEW + 1] = masks[wave];
-        if (lane < (int)G3_VIEW) {
-            const u64 wb = w0 + lane;
+        if (have) {
+            const u64 wb = w0 + (u64)j;
             Cls c = {0, 0, 0, 0, 0, 0, 0};
             u64 LS = 0;
             if (wb < nB) {
-                GuardBlk blk = {bytes, wb * 64, N};
+                const GuardBlk blk = {bytes, wb * 64, N};
                 const u64 q = wb * 64;
                 const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
-                c = classify_block_fast(blk, nvalid, dev_tables());
+                c = classify_block_fast(blk, nvalid, ut);
                 const u64 V = below(nvalid);
                 bool nrs;
                 const u64 RS = block_record_starts(offsets, rec_lo, R, N, wb, &nrs) & V;
@@ -1324,34 +1191,36 @@ __global__ __launch_bounds__(NT) void k_gate3_solve(const u8* __restrict__ bytes
                 const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
                 LS = derive(c, V, RS, next_nl, pt).LS;
             }
-            m[0][lane] = c.ws; m[1][lane] = c.pipe; m[2][lane] = c.dig; m[3][lane] = c.alp; m[4][lane] = LS;
-            m[5][lane] = 0; m[6][lane] = 0; m[7][lane] = 0;
+            gm.ws[j] = c.ws; gm.pipe[j] = c.pipe; gm.dig[j] = c.dig; gm.alp[j] = c.alp; gm.ls[j] = LS;
+            gm.G[j] = 0; gm.gPSP[j] = 0; gm.gPNL[j] = 0;
         }
-        __threadfence_block();
-        G3Masks gm = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]};
-        const u64 view0 = w0 * 64;
-        const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
-        const bool ok = g3_wave_solve(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio, tok[wave]);
-        __threadfence_block();
-        const u64 mb = ~(1ull << (p & 63));
-        if (lane == 0) {   // the marker's flag bits
+        __threadfence_block();   // the masks of a line are written by five lanes and read by the first of them
+        if (have && j == 0) {
+            const u64 view0 = w0 * 64;
+            const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
+            const bool ok = g3_lane_solve(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio);
+            const u64 mb = ~(1ull << (p & 63));   // the marker's flag bits
             atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PSP), mb);
             atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PNL), mb);
-        }
-        if (ok) {
-            if (lane < (int)G3_VIEW && m[5][lane]) {
-                const u64 wb = w0 + lane;
-                const u64 g = m[5][lane], sp = m[6][lane], nl = m[7][lane];
-                plan_or(plan, wb, g, g, sp, nl);
-                atomicAdd(&tile_bytes[wb / TILE_BLOCKS], (u32)(popc(g) + popc(sp | nl)));
-                // token starts of this block: kept bytes whose predecessor is not kept
-                const u64 prevg = lane > 0 ? m[5][lane - 1] >> 63 : 0;
-                atomicAdd(&tile_toks[wb / TILE_BLOCKS], (u32)popc(g & ~((g << 1) | prevg)));
+            if (ok) {
+                u64 prevg = 0;
+#pragma unroll 1
+                for (u32 jj = 0; jj < G3_VIEW; jj++) {
+                    const u64 g = gm.G[jj];
+                    if (g) {
+                        const u64 wb = w0 + jj, sp = gm.gPSP[jj], nl = gm.gPNL[jj];
+                        plan_or(plan, wb, g, g, sp, nl);
+                        atomicAdd(&tile_bytes[wb / TILE_BLOCKS], (u32)(popc(g) + popc(sp | nl)));
+                        // token starts of this block: kept bytes whose predecessor is not kept
+                        atomicAdd(&tile_toks[wb / TILE_BLOCKS], (u32)popc(g & ~((g << 1) | prevg)));
+                    }
+                    prevg = g >> 63;
+                }
+            } else {
+                g3_serial_solve(bytes, offsets, R, N, cfg, plan, p, table, rab, tile_bytes, tile_toks);
             }
-        } else if (lane == 0) {
-            g3_serial_solve(bytes, offsets, R, N, cfg, plan, p, table, rab, tile_bytes, tile_toks);
         }
-        __threadfence_block();
+        __threadfence_block();   // the line's lane has read the masks before the next group overwrites them
     }
 }
 
@@ -2237,7 +2106,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
                                      c->seedJ.as<J>(), c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes,
                                      ttoks, tflags, c->plan_stop()); }
             { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
+              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
                                  c->g3list.as<u64>(), totals + 6, g3_cap, tbytes, ttoks, totals); }
         } else {
             Prof pr(c, "k_count_tokens");
