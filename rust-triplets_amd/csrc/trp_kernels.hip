@@ -1414,7 +1414,7 @@ __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __res
     in.base = tile_base[t];
 }
 
-constexpr int EMIT_TPW = 4;   // consecutive tiles per workgroup
+constexpr int EMIT_TPW = 2;   // consecutive tiles per workgroup
 template <bool PASSTHROUGH>
 __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
