@@ -907,7 +907,7 @@ struct PlanShared {
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
                                               Plan* __restrict__ plan, u64* __restrict__ g3list, u64 g3cap,
