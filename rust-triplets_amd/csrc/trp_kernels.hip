@@ -1328,6 +1328,8 @@ struct EmitOp {
     }
 };
 
+// four u32 that are only 4-byte aligned in memory
+struct __attribute__((packed, aligned(4))) Quad32 { u32 x, y, z, w; };
 struct Pair32 { u32 lo, hi; };   // two consecutive dwords at a 4-byte aligned address
 
 // Once the run copies are done the input image is dead; its space then holds the staged token table and
@@ -1639,10 +1641,22 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
         u32 n_ss = sh.total.nte - ((starts_inside_token && sh.total.nte > 0) ? 1u : 0u);
         if (n_ss > TOK_CAP) n_ss = TOK_CAP;
         if (stop_after == 6) n_ss = 0;   // profiling aid: everything but the token table stores
-        for (u32 i = tid; i < n_ss; i += NT) {
-            u32 v = tokstage[i];
-            tok_start[tok0 + i] = out0 + (v & 0xFFFFu);
-            tok_len[tok0 + i] = v >> 16;
+        // four tokens per lane and store (the token arrays are only 4-byte aligned at tok0)
+        for (u32 i = tid * 4; i < n_ss; i += NT * 4) {
+            if (i + 4 <= n_ss) {
+                const uint4 v = *reinterpret_cast<const uint4*>(tokstage + i);
+                const Quad32 st = {out0 + (v.x & 0xFFFFu), out0 + (v.y & 0xFFFFu), out0 + (v.z & 0xFFFFu),
+                                   out0 + (v.w & 0xFFFFu)};
+                const Quad32 ln = {v.x >> 16, v.y >> 16, v.z >> 16, v.w >> 16};
+                *reinterpret_cast<Quad32*>(tok_start + tok0 + i) = st;
+                *reinterpret_cast<Quad32*>(tok_len + tok0 + i) = ln;
+            } else {
+                for (u32 k = i; k < n_ss; k++) {
+                    const u32 v = tokstage[k];
+                    tok_start[tok0 + k] = out0 + (v & 0xFFFFu);
+                    tok_len[tok0 + k] = v >> 16;
+                }
+            }
         }
     }
     if (stop_after == 4) { __syncthreads(); continue; }
