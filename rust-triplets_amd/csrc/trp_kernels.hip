@@ -3,7 +3,8 @@
 // Data layout in HBM (one batch = N bytes, R records, nB = ceil(N/64) blocks, nT = ceil(N/16384) tiles)
 //   bytes[N], offsets[R+1]        caller's packed corpus
 //   rec_lo[nT+2]                  first record that starts at/after each tile start (+ one for N)
-//   SA[nT]                        per-tile forward summary (struct J) written by k_summary
+//   seedJ[nT], seedS[nT]          what enters each tile from the left / right (k_seed, or k_tile_carry)
+//   SA[nT]                        per-tile forward summary (struct J) written by k_summary (fallback path)
 //   plan[nB] (4 x u64)            emit plan bit planes (struct Plan) written by k_plan / k_gate3
 //   g3list[]                      digit-heavy lines that k_plan could not solve inside a tile (position | flags)
 //   tile_bytes[nT], tile_toks[nT], tile_flags[nT]   emitted bytes / token starts per tile
@@ -11,9 +12,9 @@
 //   denoised[D], tok_start[T], tok_len[T], *_offsets[R+1], chunks[C]   results
 //
 // Kernel sequence with the denoiser enabled:
-//   k_rec_lo -> k_summary -> k_tile_carry -> k_plan -> k_gate3_solve -> k_pack_tiles -> scan(3) -> k_emit
-//   -> k_finish
-//   -> k_chunk_count -> scan(3) -> k_chunk_emit
+//   k_rec_lo -> k_seed (-> k_summary -> k_tile_carry when k_seed left tiles open) -> k_plan -> k_gate3_solve
+//   -> k_pack_tiles -> scan(3) -> k_emit
+//   -> k_finish_count -> scan(3) -> k_chunk_emit
 // and with it disabled: k_rec_lo -> k_count_tokens -> k_pack_tiles -> scan(3) -> k_emit<passthrough> ...
 //
 // The per-lane logic lives in trp_lane.h (shared with the host simulator).
@@ -1692,27 +1693,25 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
     }
 }
 
-// Totals, and the offsets of records that start at the very end of the corpus.
-__global__ void k_finish(const u64* __restrict__ tile_base, u64 nT, const u32* __restrict__ rec_lo, u64 R,
-                         u64 N, int passthrough, u64* __restrict__ den_off, u64* __restrict__ tok_off,
-                         u64* __restrict__ totals) {
+// Totals, the offsets of records that start at the very end of the corpus (k_emit only sees records that
+// start inside a tile), and per record: the number of chunks and the dropped flag.  One thread per entry
+// of the offset arrays (R + 1).
+__global__ void k_finish_count(const u64* __restrict__ tile_base, u64 nT, const u32* __restrict__ rec_lo, u64 R,
+                               u64 N, int passthrough, DevCfg cfg, u64* __restrict__ den_off,
+                               u64* __restrict__ tok_off, u64* __restrict__ totals, u64* __restrict__ counts,
+                               u8* __restrict__ dropped) {
     u64 D = nT ? (tile_base[nT] & 0xFFFFFFFFull) : 0, T = nT ? (tile_base[nT] >> 32) : 0;
     if (passthrough) D = N;
-    u64 first = rec_lo[nT + 1];   // first record whose start offset is >= N
-    u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= R) { den_off[i] = D; tok_off[i] = T; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[0] = D; totals[1] = T; }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// chunk windows
-// ---------------------------------------------------------------------------------------------------
-__global__ void k_chunk_count(const u64* __restrict__ den_off, const u64* __restrict__ tok_off, u64 R, DevCfg cfg,
-                              u64* __restrict__ counts, u8* __restrict__ dropped) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    counts[r] = chunk_count(tok_off[r + 1] - tok_off[r], cfg);
-    dropped[r] = cfg.denoise_enabled && !cfg.normalize && den_off[r + 1] == den_off[r];
+    const u64 first = rec_lo[nT + 1];   // first record whose start offset is >= N
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) { totals[0] = D; totals[1] = T; }
+    if (r > R) return;
+    if (r >= first) { den_off[r] = D; tok_off[r] = T; }
+    if (r == R) return;
+    const u64 d0 = r >= first ? D : den_off[r], t0 = r >= first ? T : tok_off[r];
+    const u64 d1 = r + 1 >= first ? D : den_off[r + 1], t1 = r + 1 >= first ? T : tok_off[r + 1];
+    counts[r] = chunk_count(t1 - t0, cfg);
+    dropped[r] = cfg.denoise_enabled && !cfg.normalize && d1 == d0;
 }
 
 // grid-stride over all chunks; the record of a chunk is found by binary search in chunk_offsets
@@ -2141,13 +2140,9 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
                                  d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
                                  den_off, tok_off, c->emit_stop()); }
     }
-    { Prof pr(c, "k_finish");
-      // all records at/after N (at least the sentinel entry R)
-      hipLaunchKernelGGL(k_finish, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nT, rec_lo, R, N,
-                         pass ? 1 : 0, den_off, tok_off, totals); }
-    { Prof pr(c, "k_chunk_count");
-      if (R) hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, den_off, tok_off, R, dc,
-                                c->counts.as<u64>(), c->dropped.as<u8>()); }
+    { Prof pr(c, "k_finish_count");
+      hipLaunchKernelGGL(k_finish_count, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nT, rec_lo, R, N,
+                         pass ? 1 : 0, dc, den_off, tok_off, totals, c->counts.as<u64>(), c->dropped.as<u8>()); }
     { Prof pr(c, "scan_chunks");
       if ((rc = scan_u64(c, c->counts.as<u64>(), R, chunk_off))) return rc; }
     { Prof pr(c, "k_chunk_emit");
