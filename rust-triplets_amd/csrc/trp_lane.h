@@ -276,6 +276,18 @@ TRP_UNROLL
 // Each rule is a range of code points that is uniformly Alphabetic (or uniformly neither class) in the
 // table; a test compares the two paths for every code point.
 TRP_HD u32 funnel_shr(u32 hi, u32 lo, int n) { return (u32)((((u64)hi << 32) | lo) >> n); }
+// Bit-sliced comparison of 32 six-bit values (plane k in b[k]) with a constant: bit i of the result says
+// whether value i is >= c.  From the lowest bit up: a one in c needs a one in the value and the lower part
+// to hold, a zero in c is satisfied by a one in the value or by the lower part.
+TRP_HD u32 planes_ge(const u32 (&b)[6], u32 c) {
+    if (c == 0) return ~0u;
+    if (c > 63) return 0u;
+    u32 r = ~0u;
+    TRP_UNROLL
+    for (int k = 0; k < 6; k++) r = ((c >> k) & 1u) ? (b[k] & r) : (b[k] | r);
+    return r;
+}
+TRP_HD u32 planes_in(const u32 (&b)[6], u32 lo, u32 hi) { return planes_ge(b, lo) & ~planes_ge(b, hi + 1u); }
 TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead, u32* alp) {
     if (!lead) return 0;
     const u32 cont = p[7] & ~p[6], contq = q[7] & ~q[6];
@@ -301,6 +313,19 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead,
         const u32 x30 = x5 & x4 & ~x3 & ~x2 & ~x1 & ~x0;                            // U+0530
         settled |= C3 | C4_CA | (CE & x_ge16) | CF | D013 | (D2 & x_ge16) | D4;
         alpha |= (C3 & ~x17) | C4_CA | (CE & x_ge16 & ~x22) | (CF & ~x36) | D013 | (D2 & x_ge16) | (D4 & ~x30);
+        const u32 semitic = L2 & l4 & (l3 | (l2 & l1 & l0));                        // leads D7-DF
+        if (semitic) {
+            const u32 xb[6] = {x0, x1, x2, x3, x4, x5};
+            const u32 D7 = hi & l2 & l1 & l0;                                       // U+05C0-05FF
+            const u32 hi2 = L2 & l4 & l3 & ~l2;                                     // leads D8-DB: U+0600-06FF
+            const u32 D8 = hi2 & ~l1 & ~l0, D9 = hi2 & ~l1 & l0, DA = hi2 & l1 & ~l0, DB = hi2 & l1 & l0;
+            const u32 heb = D7 & planes_in(xb, 0x10, 0x2A);                         // U+05D0-05EA
+            const u32 ar8 = D8 & x5;                                                // U+0620-063F
+            const u32 ar9_not = planes_in(xb, 0x18, 0x18) | planes_in(xb, 0x20, 0x2D);   // U+0658, U+0660-066D
+            const u32 arB = DB & ~planes_ge(xb, 0x14);                              // U+06C0-06D3
+            settled |= heb | ar8 | D9 | DA | arB;
+            alpha |= heb | ar8 | (D9 & ~ar9_not) | DA | arB;
+        }
     }
     const u32 L3 = lead & p[5] & ~p[4] & v1 & v2;   // 1110xxxx 10xxxxxx 10xxxxxx
     const u32 L4 = lead & p[5] & p[4] & ~p[3] & v1 & v2 & v3;
@@ -322,8 +347,29 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead,
         const u32 E2_none = E2 & ((x00 & (y5 | y4) & ~y_ws) | (x02 & y5));
         // U+1F300-1FFFF: pictographs, no letters
         const u32 F0_9F = L4 & ~l2 & ~l1 & ~l0 & ~x5 & x4 & x3 & x2 & x1 & x0 & (y5 | y4 | (y3 & y2));
-        const u32 a3 = E5_E9 | (E4 & ~x37) | (E3 & x_ge16) | EB_EC | (EA & x5 & x4) | (ED & x_lt1E);
+        u32 a3 = E5_E9 | (E4 & ~x37) | (E3 & x_ge16) | EB_EC | (EA & x5 & x4) | (ED & x_lt1E);
         settled |= a3 | E4 | E2_none | F0_9F;
+        // kana (E3 81-83), Devanagari (E0 A4-A5), Thai (E0 B8-B9): every code point of these rows is either
+        // alphabetic or in neither class
+        const u32 E0 = L3 & ~(l3 | l2 | l1 | l0);
+        const u32 E3_low = E3 & ~x_ge16 & ~(x3 | x2) & (x1 | x0);                   // second byte 81, 82, 83
+        if (E0 | E3_low) {
+            const u32 yb[6] = {y0, y1, y2, y3, y4, y5};
+            const u32 x_hi = x5 & ~x4, x_lo3 = ~x3 & x2 & ~x1;                      // second byte A4/A5: 10 010x
+            const u32 A4 = E0 & x_hi & x_lo3 & ~x0, A5 = E0 & x_hi & x_lo3 & x0;    // U+0900-093F, 0940-097F
+            const u32 xB8 = x5 & x4 & x3 & ~x2 & ~x1;                               // second byte B8/B9: 11 100x
+            const u32 B8 = E0 & xB8 & ~x0, B9 = E0 & xB8 & x0;                      // U+0E00-0E3F, 0E40-0E7F
+            const u32 K1 = E3_low & ~x1 & x0, K2 = E3_low & x1 & ~x0, K3 = E3_low & x1 & x0;
+            const u32 a_A4 = ~planes_in(yb, 0x3C, 0x3C);
+            const u32 a_A5 = ~planes_ge(yb, 0x0D) | planes_in(yb, 0x0E, 0x10) | planes_in(yb, 0x15, 0x23) | planes_ge(yb, 0x31);
+            const u32 a_B8 = planes_in(yb, 0x01, 0x3A);
+            const u32 a_B9 = ~planes_ge(yb, 0x07) | planes_in(yb, 0x0D, 0x0D);
+            const u32 a_K1 = planes_ge(yb, 0x01);
+            const u32 a_K2 = ~planes_ge(yb, 0x17) | planes_in(yb, 0x1D, 0x1F) | planes_ge(yb, 0x21);
+            const u32 a_K3 = ~planes_in(yb, 0x3B, 0x3B);
+            settled |= A4 | A5 | B8 | B9 | K1 | K2 | K3;
+            a3 |= (A4 & a_A4) | (A5 & a_A5) | (B8 & a_B8) | (B9 & a_B9) | (K1 & a_K1) | (K2 & a_K2) | (K3 & a_K3);
+        }
         alpha |= a3;
     }
     *alp |= alpha;
