@@ -657,8 +657,9 @@ __global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const
     const bool is_back = l16 < SEED_BACK;
     const int li = is_back ? l16 : l16 - SEED_BACK;
     const long long my_tb0 = (long long)((t0 + my_k) * TILE_BLOCKS);
-    // for the record starts: lane -> region (tile, side), eight lanes per region
-    const int rg_k = lane >> 3, rg_sub = lane & 7;
+    // for the record starts: lane -> window (tile, side), SEED_RG_LANES lanes per window
+    constexpr int SEED_RG_LANES = 64 / (2 * SEED_TPW);
+    const int rg_k = lane / SEED_RG_LANES, rg_sub = lane % SEED_RG_LANES;
 #pragma unroll 1
     for (int round = 0; round < SEED_ROUNDS; round++) {
         bool any_open = false;
@@ -686,13 +687,12 @@ __global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const
             u8* img = bk ? sw.tile[k].back : sw.tile[k].ahead;
             lds_store16(img + (ci >> 2) * PAD_STRIDE + (ci & 3) * 16, v);
         }
-        // ... and record starts (cleared, then set by eight lanes per window)
+        // ... and record starts (cleared, then set by the lanes of each window)
         for (int i = lane; i < SEED_TPW * (SEED_BACK + 1 + SEED_AHEAD + 1); i += 64) {
             const int k = i / (SEED_BACK + 1 + SEED_AHEAD + 1), ii = i % (SEED_BACK + 1 + SEED_AHEAD + 1);
             if (ii <= SEED_BACK) sw.tile[k].rs_back[ii] = 0; else sw.tile[k].rs_ahead[ii - SEED_BACK - 1] = 0;
         }
         {
-            static_assert(SEED_TPW * 2 == 8, "eight windows, eight lanes each");
             const int k = rg_k >> 1;
             const bool bk = (rg_k & 1) == 0;
             if ((open_mask >> rg_k) & 1u) {
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const
                     const u64 r0 = rec_lo[T0 < nT ? T0 : nT], r1 = rec_lo[T1 + 1 < nT ? T1 + 1 : nT];
                     const u64 w0 = (u64)lo_blk * 64, w1 = ((u64)hi_blk + 1) * 64;
                     u64* rs = bk ? sw.tile[k].rs_back : sw.tile[k].rs_ahead;
-                    for (u64 r = r0 + rg_sub; r < r1; r += 8) {
+                    for (u64 r = r0 + rg_sub; r < r1; r += SEED_RG_LANES) {
                         const u64 q = offsets[r];
                         if (q >= w0 && q < w1 && q < N) {
                             const u64 d = q - (u64)(first * 64);
