@@ -1714,20 +1714,32 @@ __global__ void k_finish_count(const u64* __restrict__ tile_base, u64 nT, const 
     dropped[r] = cfg.denoise_enabled && !cfg.normalize && d1 == d0;
 }
 
-// grid-stride over all chunks; the record of a chunk is found by binary search in chunk_offsets
+// One lane per record (wavefronts stride over the records): a record's first CHUNK_INLINE descriptors are
+// written by its lane, the rest of a record with many windows by the whole wavefront.
+constexpr u32 CHUNK_INLINE = 4;
 __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off, u64 R, DevCfg cfg,
                              u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals) {
     const u64 C = chunk_off[R];
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[2] = C; totals[3] = C > capacity ? 1 : 0; }
     if (C > capacity) return;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (u64)gridDim.x * blockDim.x) {
-        u64 lo = 0, hi = R;   // last r with chunk_off[r] <= i
-        while (lo < hi) {
-            u64 mid = (lo + hi) >> 1;
-            if (chunk_off[mid + 1] <= i) lo = mid + 1; else hi = mid;
+    const int lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 rb = wave * 64; rb < R; rb += nwaves * 64) {   // uniform
+        const u64 r = rb + (u64)lane;
+        u64 n = 0, T = 0, base = 0;
+        if (r < R) {
+            base = chunk_off[r];
+            n = chunk_off[r + 1] - base;
+            T = tok_off[r + 1] - tok_off[r];
         }
-        u64 r = lo;
-        chunks[i] = chunk_at(tok_off[r + 1] - tok_off[r], i - chunk_off[r], (u32)r, cfg);
+        for (u64 i = 0; i < n && i < CHUNK_INLINE; i++) chunks[base + i] = chunk_at(T, i, (u32)r, cfg);
+        u64 big = __ballot(n > CHUNK_INLINE);
+        while (big) {   // uniform
+            const int L = ctz(big);
+            big &= big - 1;
+            const u64 nn = __shfl(n, L, 64), TT = __shfl(T, L, 64), bb = __shfl(base, L, 64);
+            for (u64 i = CHUNK_INLINE + (u64)lane; i < nn; i += 64) chunks[bb + i] = chunk_at(TT, i, (u32)(rb + (u64)L), cfg);
+        }
     }
 }
 
