@@ -34,6 +34,12 @@ def main():
         rng = random.Random(seed)
         nrec = rng.choice([1, 3, 40, 300, 1200])
         recs = textgen.corpus(seed, nrec)
+        if rng.random() < 0.3:   # many scripts, edge characters of the classifier's range rules
+            recs += textgen.script_corpus(seed, max(1, nrec // 4))
+            rng.shuffle(recs)
+        if rng.random() < 0.05:  # a long letterless stretch and a long line: tile carries from the summaries
+            recs.append(("12 34\n" * rng.randint(2000, 9000) + "word\n").encode())
+            recs.append((" ".join("w%d" % i for i in range(rng.randint(3000, 9000)))).encode())
         if rng.random() < 0.3:   # glue records together: long records, many lines
             k = rng.randint(2, 50)
             recs = [b"\n".join(recs[i:i + k]) for i in range(0, len(recs), k)]
