@@ -291,7 +291,7 @@ def main():
             first = ctx.preprocess_batch_device(batches[0][0].data_ptr(), batches[0][1].data_ptr(), R, N, den, st)
             stats = {"D": int(first.n_denoised), "T": int(first.n_tokens), "C": int(first.n_chunks)}
         cfg = O.make_config(den.enabled, 0.35, True, 1024, (64,), 512)
-        cut = int(np.searchsorted(offs, min(N, 256_000_000), side="right")) - 1
+        cut = int(np.searchsorted(offs, min(N, 1_000_000_000), side="right")) - 1   # about 10 s on one core
         cut = max(cut, 1)
         sub_n = int(offs[cut])
         L = O.lib()
