@@ -634,13 +634,12 @@ TRP_HD J j_combine(const J& A, const J& B) {
 TRP_HD J lane_J(const Cls& c, const Derived& d) {
     J j;
     u32 g = 0;
-    if (d.LS == 0) {
-        j.head = range_sum(c, d, d.V);
-        j.tail = ls_empty();
-    } else {
-        int first = ctz(d.LS), last = top(d.LS);
-        j.head = range_sum(c, d, below(first));
-        j.tail = range_sum(c, d, ~below(last));
+    // two range sums on every path (lanes with and without a line start sit in the same wavefront)
+    const bool has_ls = d.LS != 0;
+    const int first = has_ls ? ctz(d.LS) : 64, last = has_ls ? top(d.LS) : 0;
+    j.head = range_sum(c, d, below(first));                 // the whole block when it has no line start
+    j.tail = range_sum(c, d, has_ls ? ~below(last) : 0ull);
+    if (has_ls) {
         g |= G_LS;
         u64 rsb = d.RS & below(last + 1);
         if (rsb) {
