@@ -101,6 +101,17 @@ void trp_destroy(trp_ctx* ctx);
 const char* trp_last_error(void);
 /* The hipStream_t the context launches on (as void*), for callers that order their own work. */
 void* trp_stream(trp_ctx* ctx);
+/* Ordering against the caller's own GPU work.  The reference needs none of this: its path is a synchronous
+ * CPU call (SlidingWindowChunker::materialize, src/chunking/sliding_window.rs:11); a device-resident
+ * replacement has to say on which stream it runs.
+ * trp_create_on_stream: like trp_create, but every kernel and copy of the context is enqueued on the
+ *   caller's `hip_stream` (a hipStream_t; NULL is the legacy default stream), so device inputs produced on
+ *   that stream need no synchronisation before a call, and later work on it sees the results.  The stream
+ *   stays the caller's: it must outlive the context and is not destroyed by trp_destroy.
+ * trp_wait_event: makes all work the context enqueues from now on wait for `hip_event` (a hipEvent_t the
+ *   caller recorded on the stream that produces the next inputs); the host does not block. */
+int trp_create_on_stream(int device, void* hip_stream, trp_ctx** out);
+int trp_wait_event(trp_ctx* ctx, void* hip_event);
 
 /* Batched path over host memory: copies the batch to the GPU, runs the kernels and copies every
  * result array back into buffers owned by the library (release them with trp_result_free).
@@ -122,8 +133,10 @@ void trp_trim_host_pool(void);
 /* Same path with the batch already resident in GPU memory (16-byte aligned `d_bytes`, device
  * `d_offsets`).  The result arrays are device pointers into buffers owned by the context; they stay
  * valid until the next call on this context.  The call returns after the kernels have completed
- * (the totals in `out` are read back).  The kernels run on the context's own stream (trp_stream):
- * whatever produces `d_bytes` / `d_offsets` on another stream must have completed before the call. */
+ * (the totals in `out` are read back).  The kernels run on the context's stream (trp_stream): inputs
+ * produced on another stream must be ordered before the call, either by creating the context on the
+ * producer's stream (trp_create_on_stream) or with an event (trp_wait_event); a context made by
+ * trp_create runs on a private non-blocking stream that waits for nothing by itself. */
 int trp_preprocess_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                 uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
                                 trp_result* out);

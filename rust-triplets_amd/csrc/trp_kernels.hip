@@ -127,6 +127,16 @@ __device__ inline T block_scan_excl_fwd(T v, Op op, T identity, T seed, T* smem,
     return res;
 }
 
+// Orders the LDS accesses of the lanes of one wavefront: everything the wave did before this point (in any
+// lane, whatever branch it sat in) is complete and visible before anything after it starts.  The wave
+// barrier is a reconvergence point the compiler may not move memory accesses across; the fence makes the
+// hardware wait for the outstanding LDS operations.
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ inline u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
 
 // ---- line carries of a tile from wave prefix sums and ballots ----------------------------------------
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const
                 }
             }
         }
-        __threadfence_block();   // the wave's own LDS writes are complete before any lane reads them
+        wave_lds_sync();   // the wave's own LDS writes are complete before any lane reads them
         // ---- classify this lane's window block
         const long long first = is_back ? my_tb0 - (long long)SEED_BACK * (round + 1)
                                         : my_tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * round;
@@ -763,7 +773,7 @@ __global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const
                               (u64)(tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * (round + 1)) >= nB;
             }
         }
-        __threadfence_block();   // every lane has read the images before the next round overwrites them
+        wave_lds_sync();   // every lane has read the images before the next round overwrites them
     }
     bool open = force_open != 0;
 #pragma unroll
@@ -1195,7 +1205,7 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
             gm.ws[j] = c.ws; gm.pipe[j] = c.pipe; gm.dig[j] = c.dig; gm.alp[j] = c.alp; gm.ls[j] = LS;
             gm.G[j] = 0; gm.gPSP[j] = 0; gm.gPNL[j] = 0;
         }
-        __threadfence_block();   // the masks of a line are written by five lanes and read by the first of them
+        __syncthreads();   // (one wavefront per workgroup) the masks of a line are written by five lanes and read by the first of them
         if (have && j == 0) {
             const u64 view0 = w0 * 64;
             const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
                 g3_serial_solve(bytes, offsets, R, N, cfg, plan, p, table, rab, tile_bytes, tile_toks);
             }
         }
-        __threadfence_block();   // the line's lane has read the masks before the next group overwrites them
+        __syncthreads();   // the line's lane has read the masks before the next group overwrites them
     }
 }
 
@@ -1860,6 +1870,7 @@ struct DevBuf {
 struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;            // false: the caller's stream (trp_create_on_stream)
     DevBuf rec_lo, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
@@ -1921,6 +1932,15 @@ struct Prof {
     }
 };
 
+// Event pairs of a profiled submit that never reached collect_device (failed midway, or repeated).
+void drop_events(trp_ctx* c) {
+    for (auto& ev : c->events) {
+        (void)hipEventDestroy(ev.second.first);
+        (void)hipEventDestroy(ev.second.second);
+    }
+    c->events.clear();
+}
+
 int make_devcfg(const trp_config* cfg, DevCfg* d) {
     if (!cfg) return fail(TRP_E_ARG, "config is null");
     if (cfg->n_overlaps > TRP_MAX_OVERLAPS) return fail(TRP_E_ARG, "more than TRP_MAX_OVERLAPS overlaps");
@@ -1969,7 +1989,7 @@ extern "C" {
 
 const char* trp_last_error(void) { return g_err.c_str(); }
 
-int trp_create(int device, trp_ctx** out) {
+static int create_ctx(int device, hipStream_t stream, bool own, trp_ctx** out) {
     if (!out) return fail(TRP_E_ARG, "out is null");
     *out = nullptr;
     int n = 0;
@@ -1981,11 +2001,32 @@ int trp_create(int device, trp_ctx** out) {
     trp_ctx* c = new trp_ctx();
     { const char* e2 = getenv("TRIPLETS_AMD_FORCE_SUMMARY"); c->force_summary = (e2 && atoi(e2)) ? 1u : 0u; }
     c->device = device;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; return fail(TRP_E_HIP, "hipStreamCreate failed"); }
+    c->owns_stream = own;
+    c->stream = stream;
+    if (own) {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(TRP_E_HIP, "hipStreamCreate failed"); }
+    }
     e = hipHostMalloc((void**)&c->h_totals, 16 * sizeof(u64), hipHostMallocDefault);
-    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(TRP_E_HIP, "hipHostMalloc failed"); }
+    if (e != hipSuccess) {
+        if (own) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(TRP_E_HIP, "hipHostMalloc failed");
+    }
     *out = c;
+    return TRP_OK;
+}
+
+int trp_create(int device, trp_ctx** out) { return create_ctx(device, nullptr, true, out); }
+
+int trp_create_on_stream(int device, void* hip_stream, trp_ctx** out) {
+    return create_ctx(device, (hipStream_t)hip_stream, false, out);
+}
+
+int trp_wait_event(trp_ctx* c, void* hip_event) {
+    if (!c || !hip_event) return fail(TRP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
     return TRP_OK;
 }
 
@@ -2001,7 +2042,7 @@ void trp_destroy(trp_ctx* c) {
                       &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list};
     for (DevBuf* b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
-    (void)hipStreamDestroy(c->stream);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -2015,8 +2056,9 @@ int trp_set_profiling(trp_ctx* c, int on) {
 
 int trp_get_profile(trp_ctx* c, trp_kernel_time* out, int cap) {
     if (!c) return fail(TRP_E_ARG, "ctx is null");
-    int n = (int)c->last_profile.size();
-    for (int i = 0; i < n && i < cap; i++) out[i] = c->last_profile[i];
+    if (cap < 0 || (cap > 0 && !out)) return fail(TRP_E_ARG, "out is null");
+    const int n = std::min((int)c->last_profile.size(), cap);
+    for (int i = 0; i < n; i++) out[i] = c->last_profile[i];
     return n;
 }
 
@@ -2050,7 +2092,9 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     c->have_last = false;
     const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE;
     const bool pass = !dc.denoise_enabled;
-    const u64 tok_cap = (N + 1) / 2 + 2;
+    // A token needs one byte, and two tokens of one record a separator byte between them: a record of n
+    // bytes holds at most (n + 1) / 2 tokens, the batch at most (N + non-empty records) / 2.
+    const u64 tok_cap = (N + std::min<u64>(R, N)) / 2 + 4;
     u64 chunk_cap = chunk_bound(N, R, dc);
     const u64 chunk_cap_limit = (u64)1 << 28;   // do not pre-allocate more than 8 GiB of descriptors
     if (chunk_cap > chunk_cap_limit) chunk_cap = chunk_cap_limit;
@@ -2092,7 +2136,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     u64* totals = c->totals.as<u64>();
     Plan* plan = c->plan.as<Plan>();
     J* SA = c->SA.as<J>();
-    c->events.clear();
+    drop_events(c);
     HIPCHK(hipMemsetAsync(totals, 0, 16 * sizeof(u64), st));
 
     {
@@ -2470,7 +2514,12 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
     HostPool& hp = host_pool();
     u64 cap_den = 0, cap_tok = 0, cap_ch = 0;          // capacities of the three data-dependent arrays
     u64 base_d = 0, base_t = 0, base_c = 0;
-    auto fail_free = [&](int code) { trp_result_free(out); return code; };
+    // on failure: copies into the result arrays may still be in flight on either stream
+    auto fail_free = [&](int code) {
+        for (trp_ctx* x : cx) (void)hipStreamSynchronize(x->stream);
+        trp_result_free(out);
+        return code;
+    };
     auto sync_all = [&]() -> int {
         for (trp_ctx* x : cx) HIPCHK(hipStreamSynchronize(x->stream));
         return TRP_OK;
@@ -2589,15 +2638,20 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         }
         return TRP_OK;
     };
-    if ((rc = grab((void**)&out->denoised, d.denoised, d.n_denoised))) return rc;
-    if ((rc = grab((void**)&out->denoised_offsets, d.denoised_offsets, (R + 1) * sizeof(u64)))) return rc;
-    if ((rc = grab((void**)&out->dropped, d.dropped, R))) return rc;
-    if ((rc = grab((void**)&out->tok_start, d.tok_start, d.n_tokens * sizeof(u32)))) return rc;
-    if ((rc = grab((void**)&out->tok_len, d.tok_len, d.n_tokens * sizeof(u32)))) return rc;
-    if ((rc = grab((void**)&out->tok_offsets, d.tok_offsets, (R + 1) * sizeof(u64)))) return rc;
-    if ((rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return rc;
-    if ((rc = grab((void**)&out->chunk_offsets, d.chunk_offsets, (R + 1) * sizeof(u64)))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // on failure: wait for the copies already enqueued, then hand the arrays taken so far back to the pool
+    auto fail_free = [&](int code) { (void)hipStreamSynchronize(c->stream); trp_result_free(out); return code; };
+    if ((rc = grab((void**)&out->denoised, d.denoised, d.n_denoised))) return fail_free(rc);
+    if ((rc = grab((void**)&out->denoised_offsets, d.denoised_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
+    if ((rc = grab((void**)&out->dropped, d.dropped, R))) return fail_free(rc);
+    if ((rc = grab((void**)&out->tok_start, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+    if ((rc = grab((void**)&out->tok_len, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+    if ((rc = grab((void**)&out->tok_offsets, d.tok_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
+    if ((rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
+    if ((rc = grab((void**)&out->chunk_offsets, d.chunk_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
+    {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail_free(fail(TRP_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)));
+    }
     return TRP_OK;
 }
 

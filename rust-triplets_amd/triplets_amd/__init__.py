@@ -63,7 +63,7 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
            "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
-           "trp_submit_batch_device", "trp_wait_batch"]
+           "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event"]
 
 _lib = None
 
@@ -86,6 +86,8 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     L.trp_last_error.restype = C.c_char_p
     L.trp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.trp_create_on_stream.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.trp_wait_event.argtypes = [C.c_void_p, C.c_void_p]
     L.trp_destroy.argtypes = [C.c_void_p]
     L.trp_stream.restype = C.c_void_p
     L.trp_stream.argtypes = [C.c_void_p]
@@ -299,14 +301,27 @@ class DeviceResult:
 
 
 class Context:
-    """One GPU context (one HIP stream).  Not thread-safe: use one per thread."""
+    """One GPU context (one HIP stream).  Not thread-safe: use one per thread.
 
-    def __init__(self, device: int = 0):
+    stream=None: the context runs on a private non-blocking stream; device inputs produced on another
+    stream must be complete (or ordered with wait_event) before a call.  stream=<hipStream_t as int>, e.g.
+    torch.cuda.current_stream().cuda_stream (0 is the legacy default stream): the context enqueues on the
+    caller's stream, so inputs produced there need no synchronisation."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
         L = load_library()
         h = C.c_void_p()
-        _check(L.trp_create(device, C.byref(h)))
+        if stream is None:
+            _check(L.trp_create(device, C.byref(h)))
+        else:
+            _check(L.trp_create_on_stream(device, C.c_void_p(int(stream)), C.byref(h)))
         self._h = h
         self._L = L
+
+    def wait_event(self, hip_event: int) -> None:
+        """Work enqueued by later calls waits for the given hipEvent_t (e.g. a recorded
+        torch.cuda.Event().cuda_event); the host does not block."""
+        _check(self._L.trp_wait_event(self._h, C.c_void_p(int(hip_event))))
 
     def close(self):
         if self._h:

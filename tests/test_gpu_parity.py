@@ -276,3 +276,72 @@ def test_tile_carries_from_windows_and_from_summaries(T, ctx):
             assert a.denoised.tobytes() == b.denoised.tobytes() and np.array_equal(a.tok_offsets, b.tok_offsets)
     finally:
         forced.close()
+
+
+def test_one_byte_records_fill_the_token_table(T, ctx):
+    """A batch of one-byte records holds as many tokens as bytes (a record start begins a token): the
+    token arrays must be sized for that, in the denoising, pass-through and normalize modes; the mixed
+    batch also takes more tokens per 64-byte block than the staged token table of a tile holds."""
+    import test_normalize as TN
+    for recs in ([b"a"] * 200_000, [b"a", b"b c", b"d", b"1", b"e f", b"", b"gh"] * 40_000,
+                 [b"x" if i % 3 else b"y z" for i in range(150_001)]):
+        for cfg in ((True, 0.35, True, 4, (1,), 2), (False, 0.35, True, 1024, (64,), 512)):
+            exp, got = _run(T, ctx, recs, cfg)
+            assert_same(exp, got, None, "one-byte records, denoiser %s" % cfg[0])
+        norm, exp = TN.expected(recs)
+        data, offs = O.pack(recs)
+        assert_same(exp, ctx.normalize_batch(data, offs), None, "one-byte records, normalize")
+
+
+def test_inputs_produced_on_the_callers_stream_need_no_sync(T):
+    """A context created on the caller's stream (here torch's current stream) is ordered after the
+    asynchronous copies that produce its inputs; a context with a private stream gets the same ordering
+    from an event.  No device-wide synchronisation anywhere before the calls."""
+    import torch
+    den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy(64, [8], 0.35, 16)
+    ocfg = O.make_config(True, 0.35, True, 64, (8,), 16)
+    recs = textgen.corpus(77, 3000) * 6
+    data, offs = O.pack(recs)
+    exp = O.batch(data, offs, ocfg, n_threads=8)
+    pin_d = torch.from_numpy(data).pin_memory()
+    pin_o = torch.from_numpy(offs.astype(np.int64)).pin_memory()
+    side = torch.cuda.Stream()
+    on_torch = T.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    on_side = T.Context(0, stream=side.cuda_stream)
+    private = T.Context(0)
+    try:
+        for rep in range(3):
+            # (1) producer = torch's current stream, context on that stream
+            filler = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+            filler.fill_(rep)                                   # keeps the stream busy ahead of the copies
+            db = torch.empty(len(data) + 64, dtype=torch.uint8, device="cuda")
+            db[:len(data)].copy_(pin_d, non_blocking=True)
+            do = pin_o.to("cuda", non_blocking=True)
+            got = on_torch.preprocess_batch_device(db.data_ptr(), do.data_ptr(), len(recs), len(data), den, st).to_host()
+            assert_same(exp, got, None, "context on torch's stream, rep %d" % rep)
+            # (2) producer = a side stream, context on the side stream
+            with torch.cuda.stream(side):
+                filler2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+                filler2.fill_(rep)
+                db2 = torch.empty(len(data) + 64, dtype=torch.uint8, device="cuda")
+                db2[:len(data)].copy_(pin_d, non_blocking=True)
+                do2 = pin_o.to("cuda", non_blocking=True)
+            got = on_side.preprocess_batch_device(db2.data_ptr(), do2.data_ptr(), len(recs), len(data), den, st).to_host()
+            assert_same(exp, got, None, "context on a side stream, rep %d" % rep)
+            # (3) producer = the side stream, private-stream context ordered by an event
+            with torch.cuda.stream(side):
+                filler2.fill_(rep + 1)
+                db3 = torch.empty(len(data) + 64, dtype=torch.uint8, device="cuda")
+                db3[:len(data)].copy_(pin_d, non_blocking=True)
+                do3 = pin_o.to("cuda", non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            private.wait_event(ev.cuda_event)
+            got = private.preprocess_batch_device(db3.data_ptr(), do3.data_ptr(), len(recs), len(data), den, st).to_host()
+            assert_same(exp, got, None, "private stream after an event, rep %d" % rep)
+            side.synchronize()
+            torch.cuda.current_stream().synchronize()
+    finally:
+        on_torch.close()
+        on_side.close()
+        private.close()
