@@ -181,7 +181,9 @@ __device__ inline LineSum unpack_ls(u32 da, u32 p, u32 f) {
 }
 
 struct WaveLines {
-    u32 Ix_da, Ix_p, Ih_da, Ih_p;   // inclusive prefix sums over the lanes: x and h, digits | alpha << 16, pipes
+    u32 Ix_da, Ix_p;                // inclusive prefix sums of x over the lanes: digits | alpha << 16, pipes
+    u32 Z_da, Z_p;                  // exclusive prefix sum of x plus the lane's own h: the sum of h over the lanes
+                                    // up to this one when no lane before it has a line start (then x = h there)
     u32 x_da, x_p;                  // the lane's own x
     u64 lsm, rsm, gah, gat, c0m, c1m;
     FlagBallots xb, hb;
@@ -199,8 +201,8 @@ __device__ inline WaveLines wave_lines(const J& j) {
     W.x_p = x.p;
     W.Ix_da = wave_incl_scan_add(W.x_da);
     W.Ix_p = wave_incl_scan_add(W.x_p);
-    W.Ih_da = wave_incl_scan_add(j.head.d | (j.head.a << 16));
-    W.Ih_p = wave_incl_scan_add(j.head.p);
+    W.Z_da = W.Ix_da - W.x_da + (j.head.d | (j.head.a << 16));
+    W.Z_p = W.Ix_p - W.x_p + j.head.p;
     W.lsm = __ballot(has_ls);
     W.rsm = __ballot((j.g & G_RS) != 0);
     W.gah = __ballot((j.g & G_AH) != 0);
@@ -218,14 +220,15 @@ __device__ inline J wave_range_total(const WaveLines& W, int lo, int hi) {
     u32 g = 0;
     const u64 m = below(hi) & ~below(lo);
     const u64 lsm = W.lsm & m, rsm = W.rsm & m, gah = W.gah & m, gat = W.gat & m;
-    const u32 h_lo_da = lo > 0 ? readlane_u32(W.Ih_da, lo - 1) : 0u, h_lo_p = lo > 0 ? readlane_u32(W.Ih_p, lo - 1) : 0u;
+    // the lanes of the range before its first line start have x = h, so sums of h are differences of Ix / Z
+    const u32 h_lo_da = lo > 0 ? readlane_u32(W.Ix_da, lo - 1) : 0u, h_lo_p = lo > 0 ? readlane_u32(W.Ix_p, lo - 1) : 0u;
     if (!lsm) {
-        r.head = unpack_ls(readlane_u32(W.Ih_da, hi - 1) - h_lo_da, readlane_u32(W.Ih_p, hi - 1) - h_lo_p,
+        r.head = unpack_ls(readlane_u32(W.Ix_da, hi - 1) - h_lo_da, readlane_u32(W.Ix_p, hi - 1) - h_lo_p,
                            flags_of(W.hb, m));
         r.tail = ls_empty();
     } else {
         const int f = ctz(lsm), l = top(lsm);
-        r.head = unpack_ls(readlane_u32(W.Ih_da, f) - h_lo_da, readlane_u32(W.Ih_p, f) - h_lo_p,
+        r.head = unpack_ls(readlane_u32(W.Z_da, f) - h_lo_da, readlane_u32(W.Z_p, f) - h_lo_p,
                            flags_of(W.hb, m & below(f + 1)));
         const u32 before_da = l > 0 ? readlane_u32(W.Ix_da, l - 1) : 0u, before_p = l > 0 ? readlane_u32(W.Ix_p, l - 1) : 0u;
         r.tail = unpack_ls(readlane_u32(W.Ix_da, hi - 1) - before_da, readlane_u32(W.Ix_p, hi - 1) - before_p,
@@ -299,8 +302,13 @@ __device__ inline LaneCarry wave_carry(const WaveLines& W, const J& Pw, const S&
     const u64 afterL = ~below(L + 1);
     const u64 eb = W.lsm & afterL;
     const int e = eb ? ctz(eb) : 63;
-    const u32 at_e_da = lane_read(W.Ih_da, e), at_e_p = lane_read(W.Ih_p, e);
-    const LineSum fwd = unpack_ls(at_e_da - W.Ih_da, at_e_p - W.Ih_p, flags_of(W.hb, afterL & below(e + 1)));
+    // sum of h over the lanes (L, e]: the lanes between have no line start (x = h), lane e adds its own h
+    // (with no line start after this lane it is the sum of x over the remaining lanes)
+    // (the cross-lane reads are made by every lane, outside the selects: a lane may be another lane's source)
+    const u32 ze_da = lane_read(W.Z_da, e), ze_p = lane_read(W.Z_p, e);
+    const u32 all_da = readlane_u32(W.Ix_da, 63), all_p = readlane_u32(W.Ix_p, 63);
+    const u32 at_e_da = sel32(eb != 0, ze_da, all_da), at_e_p = sel32(eb != 0, ze_p, all_p);
+    const LineSum fwd = unpack_ls(at_e_da - W.Ix_da, at_e_p - W.Ix_p, flags_of(W.hb, afterL & below(e + 1)));
     k.co = eb ? fwd : ls_add(fwd, Xw.head);
     k.next_rs = next_rs;
     return k;
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(NT) void k_tile_carry(const J* __restrict__ SA, u64
 
 // ---- digit-heavy lines solved inside the tile (one wavefront per line) ---------------------------
 constexpr u32 G3_LCAP = 1024;   // lines per tile that can be listed in LDS
-constexpr u32 G3_MAXW = 4;      // a line may touch at most this many 64-byte blocks; longer ones are walked serially
+constexpr u32 G3_MAXW = G3_WORDS;   // the mask solver takes lines of up to 64 * G3_MAXW bytes; longer ones are walked serially
 
 
 // Per-block masks of the tile, kept in the LDS region of the (no longer needed) byte image.
@@ -843,48 +851,44 @@ struct G3Masks {
 };
 
 // One digit-heavy line (gate 3, reference strip_digit_tokens, denoiser_preprocessor.rs:70-140) solved by a
-// single lane (64 lines per wave at a time) with g3_bits_solve: no walk over the tokens, no limit on their
-// number.  The mask arrays are indexed by block number within a view of n_words blocks; s is the position
-// of the line's first byte in the view and corpus_end the position where the corpus ends (or ~0 when that
-// is outside the view).  Returns false when the line does not fit (more than G3_WORDS blocks).
-static_assert(G3_WORDS == (int)G3_MAXW, "the lane solver and the wave solver take the same lines");
+// single lane (64 lines per wave at a time) with the mask solver of W words: no walk over the tokens, no
+// limit on their number.  The mask arrays are indexed by block number within a view of n_words blocks; s is
+// the position of the line's first byte in the view and corpus_end the position where the corpus ends (or ~0
+// when that is outside the view).  Returns false when the line does not fit (its end is not in the view, or
+// it is longer than 64 * W bytes).
+template <int W>
 __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
                                      float max_ratio) {
     const u32 w0 = s >> 6;
     u32 e = 0xFFFFFFFFu;
-    for (u32 w = w0; w <= w0 + G3_MAXW && w < n_words; w++) {
+    for (u32 w = w0; w <= w0 + W && w < n_words; w++) {   // the next line start, if it is close enough
         u64 m = a.ls[w];
         if (w == w0) m &= ~below((int)(s & 63u) + 1);
         if (m) { e = w * 64u + (u32)ctz(m); break; }
     }
     if (e == 0xFFFFFFFFu) {
-        if (corpus_end != 0xFFFFFFFFu && corpus_end <= (w0 + G3_MAXW) * 64u) e = corpus_end;
+        if (corpus_end != 0xFFFFFFFFu && corpus_end <= (w0 + W + 1) * 64u) e = corpus_end;
         else return false;
     }
-    const u32 w1 = (e - 1u) >> 6;
-    if (w1 - w0 >= G3_MAXW) return false;
-    G3Bits X, DG, AL;
-#pragma unroll
-    for (u32 j = 0; j < G3_MAXW; j++) {
-        X.w[j] = DG.w[j] = AL.w[j] = 0;
-        const u32 w = w0 + j;
-        if (w <= w1) {
-            u64 range = ~0ull;
-            if (j == 0) range &= ~below((int)(s & 63u));
-            if (w == w1 && (e & 63u)) range &= below((int)(e & 63u));
-            X.w[j] = ~(a.ws[w] | (table ? a.pipe[w] : 0ull)) & range;
-            DG.w[j] = a.dig[w] & range;
-            AL.w[j] = a.alp[w] & range;
-        }
-    }
-    const G3Bits K = g3_bits_solve(X, DG, AL, max_ratio);
-    const G3Bits KS = g3b_run_starts(K);   // kept tokens are whole tokens: their starts are the runs' starts of K & X
+    if (e - s > 64u * W) return false;
+    u64 K[W + 1], KS[W + 1];
+    g3_solve_shifted<W>(
+        [&](u32 w) -> G3Src {
+            G3Src r = {0, 0, 0};
+            if (w < n_words) {
+                r.x = ~(a.ws[w] | (table ? a.pipe[w] : 0ull));
+                r.dg = a.dig[w];
+                r.al = a.alp[w];
+            }
+            return r;
+        },
+        s, e, max_ratio, K, KS);
     bool first = true;
 #pragma unroll
-    for (u32 j = 0; j < G3_MAXW; j++) {
-        const u64 g = K.w[j];
+    for (u32 j = 0; j <= (u32)W; j++) {
+        const u64 g = K[j];
         if (g) {
-            u64 psp = KS.w[j], pnl = 0;
+            u64 psp = KS[j], pnl = 0;
             if (first && psp) {
                 const u64 low = psp & (0ull - psp);
                 psp &= ~low;
@@ -1000,7 +1004,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const u32 tile_valid = (u32)(N - tS < (u64)TILE ? N - tS : (u64)TILE);
             for (u32 i = tid; i < nl; i += NT) {   // one line per lane
                 const u32 ent = sh.list[i], s0 = ent & 0x3FFFu;
-                if (g3_lane_solve(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
+                // lines of more than 128 bytes are left for k_gate3_solve
+                if (g3_lane_solve<G3_SHORT>(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
                                   tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, cfg.max_digit_ratio))
                     atomicAnd(reinterpret_cast<unsigned long long*>(&sh.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
             }
@@ -1209,7 +1214,7 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
         if (have && j == 0) {
             const u64 view0 = w0 * 64;
             const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
-            const bool ok = g3_lane_solve(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio);
+            const bool ok = g3_lane_solve<G3_WORDS>(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio);
             const u64 mb = ~(1ull << (p & 63));   // the marker's flag bits
             atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PSP), mb);
             atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PNL), mb);

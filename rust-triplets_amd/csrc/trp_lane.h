@@ -288,7 +288,8 @@ TRP_HD u32 planes_ge(const u32 (&b)[6], u32 c) {
     return r;
 }
 TRP_HD u32 planes_in(const u32 (&b)[6], u32 lo, u32 hi) { return planes_ge(b, lo) & ~planes_ge(b, hi + 1u); }
-TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead, u32* alp) {
+// *ws2 / *ws3 receive the lead bytes of the two- and three-byte White_Space characters among the settled ones.
+TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead, u32* alp, u32* ws2, u32* ws3) {
     if (!lead) return 0;
     const u32 cont = p[7] & ~p[6], contq = q[7] & ~q[6];
     const u32 v1 = funnel_shr(contq, cont, 1), v2 = funnel_shr(contq, cont, 2), v3 = funnel_shr(contq, cont, 3);
@@ -313,6 +314,16 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead,
         const u32 x30 = x5 & x4 & ~x3 & ~x2 & ~x1 & ~x0;                            // U+0530
         settled |= C3 | C4_CA | (CE & x_ge16) | CF | D013 | (D2 & x_ge16) | D4;
         alpha |= (C3 & ~x17) | C4_CA | (CE & x_ge16 & ~x22) | (CF & ~x36) | D013 | (D2 & x_ge16) | (D4 & ~x30);
+        const u32 C2 = lo & ~l3 & ~l2 & l1 & ~l0;                                   // U+0080-00BF
+        if (C2) {
+            // letters U+00AA, 00B5, 00BA; whitespace U+0085, 00A0; the rest of the row is in neither class
+            const u32 x2A = x5 & ~x4 & x3 & ~x2 & x1 & ~x0, x35 = x5 & x4 & ~x3 & x2 & ~x1 & x0,
+                      x3A = x5 & x4 & x3 & ~x2 & x1 & ~x0;
+            const u32 x05 = ~(x5 | x4 | x3 | x1) & x2 & x0, x20 = x5 & ~(x4 | x3 | x2 | x1 | x0);
+            settled |= C2;
+            alpha |= C2 & (x2A | x35 | x3A);
+            *ws2 |= C2 & (x05 | x20);
+        }
         const u32 semitic = L2 & l4 & (l3 | (l2 & l1 & l0));                        // leads D7-DF
         if (semitic) {
             const u32 xb[6] = {x0, x1, x2, x3, x4, x5};
@@ -345,14 +356,21 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead,
         const u32 y_ws = y5 & ~y4 & y3 & ((~y2 & ~y1) | (y2 & y1 & y0));            // U+2028, 2029, 202F
         // U+2010-203F without the three whitespace characters, U+20A0-20BF: punctuation and currency signs
         const u32 E2_none = E2 & ((x00 & (y5 | y4) & ~y_ws) | (x02 & y5));
+        // U+2000-200F: eleven spaces (U+2000-200A), then format characters in neither class
+        const u32 E2_00 = E2 & x00 & ~(y5 | y4);
+        *ws3 |= (E2 & x00 & y_ws) | (E2_00 & ~(y3 & (y2 | (y1 & y0))));
         // U+1F300-1FFFF: pictographs, no letters
         const u32 F0_9F = L4 & ~l2 & ~l1 & ~l0 & ~x5 & x4 & x3 & x2 & x1 & x0 & (y5 | y4 | (y3 & y2));
         u32 a3 = E5_E9 | (E4 & ~x37) | (E3 & x_ge16) | EB_EC | (EA & x5 & x4) | (ED & x_lt1E);
-        settled |= a3 | E4 | E2_none | F0_9F;
+        settled |= a3 | E4 | E2_none | (E2 & x00 & y_ws) | E2_00 | F0_9F;
         // kana (E3 81-83), Devanagari (E0 A4-A5), Thai (E0 B8-B9): every code point of these rows is either
         // alphabetic or in neither class
         const u32 E0 = L3 & ~(l3 | l2 | l1 | l0);
         const u32 E3_low = E3 & ~x_ge16 & ~(x3 | x2) & (x1 | x0);                   // second byte 81, 82, 83
+        // U+3000-301F without U+3005-3007: the ideographic space, then punctuation in neither class
+        const u32 E3_00 = E3 & x00 & ~y5 & ~(~y4 & ~y3 & y2 & (y1 | y0));
+        settled |= E3_00;
+        *ws3 |= E3_00 & ~(y4 | y3 | y2 | y1 | y0);
         if (E0 | E3_low) {
             const u32 yb[6] = {y0, y1, y2, y3, y4, y5};
             const u32 x_hi = x5 & ~x4, x_lo3 = ~x3 & x2 & ~x1;                      // second byte A4/A5: 10 010x
@@ -396,11 +414,14 @@ TRP_UNROLL
         u32 lo[8], hi[8], zero[8];
 TRP_UNROLL
         for (int k = 0; k < 8; k++) { lo[k] = (u32)b[k]; hi[k] = (u32)(b[k] >> 32); zero[k] = 0; }
-        u32 alp_lo = 0, alp_hi = 0;
-        const u32 s_lo = classify_leads_planes(lo, hi, (u32)lead, &alp_lo);
-        const u32 s_hi = classify_leads_planes(hi, zero, (u32)(lead >> 32) & 0x1FFFFFFFu, &alp_hi);   // ends by byte 63
+        u32 alp_lo = 0, alp_hi = 0, ws2_lo = 0, ws2_hi = 0, ws3_lo = 0, ws3_hi = 0;
+        const u32 s_lo = classify_leads_planes(lo, hi, (u32)lead, &alp_lo, &ws2_lo, &ws3_lo);
+        const u32 s_hi = classify_leads_planes(hi, zero, (u32)(lead >> 32) & 0x1FFFFFFFu, &alp_hi, &ws2_hi, &ws3_hi);   // ends by byte 63
         mb_alp = (u64)alp_lo | ((u64)alp_hi << 32);
         lead &= ~((u64)s_lo | ((u64)s_hi << 32));
+        // a whitespace character marks all its bytes
+        const u64 w3 = (u64)ws3_lo | ((u64)ws3_hi << 32), w23 = w3 | (u64)ws2_lo | ((u64)ws2_hi << 32);
+        mb_ws = (w23 | (w23 << 1) | (w3 << 2)) & V;
     }
     while (lead) {
         const int j = ctz(lead);
@@ -812,55 +833,55 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         have_table_masks = true;
     };
 
-    int s = 0;
-    bool is_head = head0;
-    for (;;) {
-        u64 nxt = d.LS & ~below(s + 1);
-        int e = nxt ? ctz(nxt) : 64;
-        u64 R = below(e) & ~below(s) & d.V;
-        if (R) {
-            LineSum tot = range_sum(c, d, R);
-            if (is_head) tot = ls_add(k.ci, tot);
-            if (!nxt) tot = ls_add(tot, k.co);
-            if (tot.a > 0) {
-                bool rab;
-                if (is_head) rab = k.ci_rab;
-                else {
-                    u64 rsb = d.RS & below(s + 1);
-                    if (rsb) rab = (c.alp & below(s) & ~below(top(rsb))) != 0;
-                    else rab = k.ar_in || (c.alp & below(s)) != 0;
+    // One iteration per line that touches the block: the line that runs into it (bit 0 stands for it) and the
+    // lines that start in it, without the empty ones (a line start that sits on its own terminator: nothing
+    // of such a line is ever emitted).
+    u64 todo = (d.LS & ~(d.TERM | d.DEL)) | (head0 ? 1ull : 0ull);
+    while (todo) {
+        const int s = ctz(todo);
+        todo &= todo - 1;
+        const bool is_head = head0 && s == 0;
+        const u64 nxt = d.LS & ~below(s + 1);
+        const int e = nxt ? ctz(nxt) : 64;
+        const u64 R = below(e) & ~below(s) & d.V;
+        LineSum tot = range_sum(c, d, R);
+        if (is_head) tot = ls_add(k.ci, tot);
+        if (!nxt) tot = ls_add(tot, k.co);
+        if (tot.a > 0) {
+            bool rab;
+            if (is_head) rab = k.ci_rab;
+            else {
+                u64 rsb = d.RS & below(s + 1);
+                if (rsb) rab = (c.alp & below(s) & ~below(top(rsb))) != 0;
+                else rab = k.ar_in || (c.alp & below(s)) != 0;
+            }
+            bool table = cfg.strip_markdown && ls_first(tot) == 1u && tot.p >= 2u;
+            bool g3 = ratio_exceeds(tot.d, tot.a, cfg.max_digit_ratio);
+            if (g3) {
+                if (!is_head) {
+                    out.TOK |= bit(s);
+                    if (table) out.PSP |= bit(s);
+                    if (rab) out.PNL |= bit(s);
                 }
-                bool table = cfg.strip_markdown && ls_first(tot) == 1u && tot.p >= 2u;
-                bool g3 = ratio_exceeds(tot.d, tot.a, cfg.max_digit_ratio);
-                if (g3) {
-                    if (!is_head) {
-                        out.TOK |= bit(s);
-                        if (table) out.PSP |= bit(s);
-                        if (rab) out.PNL |= bit(s);
-                    }
-                } else if (!table) {
-                    out.C |= d.LC & R;
-                    out.TOK |= d.LC & R & ~c.ws;
-                    if (!is_head && rab) out.PNL |= bit(s);
-                } else {
-                    if (!have_table_masks) table_masks();
-                    out.C |= R & (T | IW);
-                    out.TOK |= R & T;
-                    u64 cs = CS & R, Tr = T & R;
-                    if (Tr) {
-                        u64 first = Tr & (~Tr + 1ull);
-                        if (is_head && ls_seen_text(k.ci)) out.PSP |= cs;
-                        else {
-                            out.PSP |= cs & ~first;
-                            if (rab && (cs & first)) out.PNL |= first;
-                        }
+            } else if (!table) {
+                out.C |= d.LC & R;
+                out.TOK |= d.LC & R & ~c.ws;
+                if (!is_head && rab) out.PNL |= bit(s);
+            } else {
+                if (!have_table_masks) table_masks();
+                out.C |= R & (T | IW);
+                out.TOK |= R & T;
+                u64 cs = CS & R, Tr = T & R;
+                if (Tr) {
+                    u64 first = Tr & (~Tr + 1ull);
+                    if (is_head && ls_seen_text(k.ci)) out.PSP |= cs;
+                    else {
+                        out.PSP |= cs & ~first;
+                        if (rab && (cs & first)) out.PNL |= first;
                     }
                 }
             }
         }
-        if (!nxt) break;
-        s = e;
-        is_head = false;
     }
     plan_fold_prefixes(out, c.sp, c.nl, d.V);
     return out;
@@ -1088,15 +1109,17 @@ TRP_HD u64 g3_solve_K(ByteSrc& s, u64 p, u64 e, bool table, float max_ratio, con
 }
 
 // ---- gate 3 on bit masks -----------------------------------------------------------------------------
-// A line of at most G3_WORDS blocks solved without walking its tokens: every set of tokens is the mask of
-// its bytes (bit i = byte i of the first block of the line, G3_WORDS x 64 bits), and "the token after /
-// before a kept token" is found with carry chains.  Adding a point to a mask of runs of ones clears the
-// run from the point upwards and sets the first zero above it; the mirror image (bits reversed) does the
-// same downwards.
-constexpr int G3_WORDS = 4;
-struct G3Bits {
-    u64 w[G3_WORDS];
+// A line of at most 64 * W bytes solved without walking its tokens: every set of tokens is the mask of its
+// bytes (bit i = byte i of the line, W x 64 bits), and "the token after / before a kept token" is found
+// with carry chains.  Adding a point to a mask of runs of ones clears the run from the point upwards and
+// sets the first zero above it; the mirror image (bits reversed) does the same downwards.
+constexpr int G3_WORDS = 4;    // longest line the mask solver takes: 256 bytes (longer ones are walked serially)
+constexpr int G3_SHORT = 2;    // lines of at most 128 bytes (nearly all) take the solver of half the width
+template <int W>
+struct G3BitsT {
+    u64 w[W];
 };
+typedef G3BitsT<G3_WORDS> G3Bits;
 TRP_HD u64 bitrev64(u64 x) {
 #if defined(__clang__)
     return __builtin_bitreverse64(x);
@@ -1107,21 +1130,23 @@ TRP_HD u64 bitrev64(u64 x) {
     return __builtin_bswap64(x);
 #endif
 }
-TRP_HD G3Bits g3b_rev(const G3Bits& a) {
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_rev(const G3BitsT<W>& a) {
+    G3BitsT<W> r;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) r.w[j] = bitrev64(a.w[G3_WORDS - 1 - j]);
+    for (int j = 0; j < W; j++) r.w[j] = bitrev64(a.w[W - 1 - j]);
     return r;
 }
-TRP_HD G3Bits g3b_add(const G3Bits& a, const G3Bits& b) {
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_add(const G3BitsT<W>& a, const G3BitsT<W>& b) {
+    G3BitsT<W> r;
 #if defined(__clang__)
     unsigned long long c = 0;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) r.w[j] = __builtin_addcll(a.w[j], b.w[j], c, &c);
+    for (int j = 0; j < W; j++) r.w[j] = __builtin_addcll(a.w[j], b.w[j], c, &c);
 #else
     u64 c = 0;
-    for (int j = 0; j < G3_WORDS; j++) {
+    for (int j = 0; j < W; j++) {
         const u64 s1 = a.w[j] + b.w[j], s2 = s1 + c;
         c = (u64)(s1 < a.w[j]) | (u64)(s2 < s1);
         r.w[j] = s2;
@@ -1129,84 +1154,95 @@ TRP_HD G3Bits g3b_add(const G3Bits& a, const G3Bits& b) {
 #endif
     return r;
 }
-TRP_HD G3Bits g3b_and(const G3Bits& a, const G3Bits& b) {
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_and(const G3BitsT<W>& a, const G3BitsT<W>& b) {
+    G3BitsT<W> r;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] & b.w[j];
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] & b.w[j];
     return r;
 }
-TRP_HD G3Bits g3b_andn(const G3Bits& a, const G3Bits& b) {   // a & ~b
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_andn(const G3BitsT<W>& a, const G3BitsT<W>& b) {   // a & ~b
+    G3BitsT<W> r;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] & ~b.w[j];
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] & ~b.w[j];
     return r;
 }
-TRP_HD G3Bits g3b_or(const G3Bits& a, const G3Bits& b) {
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_or(const G3BitsT<W>& a, const G3BitsT<W>& b) {
+    G3BitsT<W> r;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] | b.w[j];
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] | b.w[j];
     return r;
 }
-TRP_HD G3Bits g3b_orn(const G3Bits& a, const G3Bits& b) {   // a | ~b
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_orn(const G3BitsT<W>& a, const G3BitsT<W>& b) {   // a | ~b
+    G3BitsT<W> r;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) r.w[j] = a.w[j] | ~b.w[j];
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] | ~b.w[j];
     return r;
 }
-TRP_HD bool g3b_any(const G3Bits& a) {
+template <int W>
+TRP_HD bool g3b_any(const G3BitsT<W>& a) {
     u64 x = 0;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) x |= a.w[j];
+    for (int j = 0; j < W; j++) x |= a.w[j];
     return x != 0;
 }
-TRP_HD u32 g3b_popc_and(const G3Bits& a, const G3Bits& b) {
+template <int W>
+TRP_HD u32 g3b_popc_and(const G3BitsT<W>& a, const G3BitsT<W>& b) {
     u32 n = 0;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) n += (u32)popc(a.w[j] & b.w[j]);
+    for (int j = 0; j < W; j++) n += (u32)popc(a.w[j] & b.w[j]);
     return n;
 }
 // first bytes / last bytes of the runs of ones
-TRP_HD G3Bits g3b_run_starts(const G3Bits& x) {
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_run_starts(const G3BitsT<W>& x) {
+    G3BitsT<W> r;
     u64 c = 0;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) {
+    for (int j = 0; j < W; j++) {
         r.w[j] = x.w[j] & ~((x.w[j] << 1) | c);
         c = x.w[j] >> 63;
     }
     return r;
 }
-TRP_HD G3Bits g3b_run_ends(const G3Bits& x) {
-    G3Bits r;
+template <int W>
+TRP_HD G3BitsT<W> g3b_run_ends(const G3BitsT<W>& x) {
+    G3BitsT<W> r;
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) {
-        const u64 nx = j + 1 < G3_WORDS ? x.w[j + 1] << 63 : 0ull;
+    for (int j = 0; j < W; j++) {
+        const u64 nx = j + 1 < W ? x.w[j + 1] << 63 : 0ull;
         r.w[j] = x.w[j] & ~((x.w[j] >> 1) | nx);
     }
     return r;
 }
 // the bytes from each point (at most one per run, inside a run of x) to the end of its run
-TRP_HD G3Bits g3b_run_from(const G3Bits& x, const G3Bits& points) { return g3b_andn(x, g3b_add(x, points)); }
+template <int W>
+TRP_HD G3BitsT<W> g3b_run_from(const G3BitsT<W>& x, const G3BitsT<W>& points) { return g3b_andn(x, g3b_add(x, points)); }
 
-// The bytes of the tokens that strip_digit_tokens keeps (denoiser_preprocessor.rs:70-140).  X: bytes of
-// the line's tokens; DG / AL: its ASCII digits / alphabetic characters (one bit per character).
 // Keeps the compiler from carrying loop-invariant derived masks (mirror images, run starts) in registers
 // across the expansion loop: they are cheap to recompute and the kernel's occupancy depends on it.
-TRP_HD void g3b_opaque(G3Bits& x) {
+template <int W>
+TRP_HD void g3b_opaque(G3BitsT<W>& x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     TRP_UNROLL
-    for (int j = 0; j < G3_WORDS; j++) asm volatile("" : "+v"(x.w[j]));
+    for (int j = 0; j < W; j++) asm volatile("" : "+v"(x.w[j]));
 #else
     (void)x;
 #endif
 }
-TRP_HD G3Bits g3_bits_solve(G3Bits X, const G3Bits& DG, const G3Bits& AL, float max_ratio) {
+// The bytes of the tokens that strip_digit_tokens keeps (denoiser_preprocessor.rs:70-140).  X: bytes of
+// the line's tokens; DG / AL: its ASCII digits / alphabetic characters (one bit per character).
+template <int W>
+TRP_HD G3BitsT<W> g3_bits_solve(G3BitsT<W> X, const G3BitsT<W>& DG, const G3BitsT<W>& AL, float max_ratio) {
     // seed: the tokens with a letter.  P = the first letter of each such token (the carry from the token
     // start runs through the letterless bytes Y and stops on a letter or on the separator after the token)
-    G3Bits K;
+    G3BitsT<W> K;
     {
-        const G3Bits Y = g3b_andn(X, AL);
-        const G3Bits P = g3b_and(g3b_andn(g3b_add(Y, g3b_run_starts(X)), Y), AL);
+        const G3BitsT<W> Y = g3b_andn(X, AL);
+        const G3BitsT<W> P = g3b_and(g3b_andn(g3b_add(Y, g3b_run_starts(X)), Y), AL);
         K = g3b_or(g3b_run_from(X, P), g3b_rev(g3b_run_from(g3b_rev(X), g3b_rev(P))));
     }
     const u32 a0 = g3b_popc_and(AL, X);
@@ -1216,21 +1252,56 @@ TRP_HD G3Bits g3_bits_solve(G3Bits X, const G3Bits& DG, const G3Bits& AL, float 
         // Z: kept bytes and everything that is not a token; a carry from a kept token's first (last) byte
         // stops on the first (last) byte of the next (previous) token that is not kept.  The kept tokens
         // are the runs of K.
-        const G3Bits Z = g3b_orn(K, X);
-        const G3Bits NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
-        G3Bits W = g3b_run_from(X, NS);
+        const G3BitsT<W> Z = g3b_orn(K, X);
+        const G3BitsT<W> NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
+        G3BitsT<W> Wv = g3b_run_from(X, NS);
         {
-            const G3Bits rZ = g3b_rev(Z);
-            const G3Bits rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
-            W = g3b_or(W, g3b_rev(g3b_run_from(g3b_rev(X), rPE)));
+            const G3BitsT<W> rZ = g3b_rev(Z);
+            const G3BitsT<W> rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
+            Wv = g3b_or(Wv, g3b_rev(g3b_run_from(g3b_rev(X), rPE)));
         }
-        if (!g3b_any(W)) break;
-        const u32 wd = g3b_popc_and(DG, W);
+        if (!g3b_any(Wv)) break;
+        const u32 wd = g3b_popc_and(DG, Wv);
         if (ratio_exceeds(d0 + wd, a0, max_ratio)) break;
         d0 += wd;
-        K = g3b_or(K, W);
+        K = g3b_or(K, Wv);
     }
     return K;
+}
+
+// The same for a line given by its place in a row of block words: the line occupies bits [s, e) of the row
+// (word k = bits 64k .. 64k+63), 0 < e - s <= 64 * W.  src(k) returns the masks of word k of the row (token
+// bytes, digits, letters; anything outside the line is ignored, words the caller does not have are zero).  The
+// line is moved down to bit 0, solved in W words, and the answer moved back: K[j] / KS[j] are the kept bytes /
+// the first bytes of the kept tokens in word (s >> 6) + j of the row.
+struct G3Src {
+    u64 x, dg, al;
+};
+template <int W, class F>
+TRP_HD void g3_solve_shifted(F src, u32 s, u32 e, float max_ratio, u64 (&K)[W + 1], u64 (&KS)[W + 1]) {
+    const u32 w0 = s >> 6, len = e - s;
+    const int o = (int)(s & 63u);
+    G3BitsT<W> X, DG, AL;
+    G3Src cur = src(w0);
+    TRP_UNROLL
+    for (int j = 0; j < W; j++) {
+        const G3Src nx = src(w0 + (u32)j + 1u);
+        const u32 lo = 64u * (u32)j;
+        const u64 m = len >= lo + 64u ? ~0ull : (len > lo ? below((int)(len - lo)) : 0ull);
+        X.w[j] = (o ? (cur.x >> o) | (nx.x << (64 - o)) : cur.x) & m;
+        DG.w[j] = (o ? (cur.dg >> o) | (nx.dg << (64 - o)) : cur.dg) & m;
+        AL.w[j] = (o ? (cur.al >> o) | (nx.al << (64 - o)) : cur.al) & m;
+        cur = nx;
+    }
+    const G3BitsT<W> Kb = g3_bits_solve(X, DG, AL, max_ratio);
+    const G3BitsT<W> Sb = g3b_run_starts(Kb);   // kept tokens are whole tokens: the runs of Kb
+    TRP_UNROLL
+    for (int j = 0; j <= W; j++) {
+        const u64 a = j < W ? Kb.w[j < W ? j : 0] : 0ull, b = j > 0 ? Kb.w[j > 0 ? j - 1 : 0] : 0ull;
+        const u64 sa = j < W ? Sb.w[j < W ? j : 0] : 0ull, sb = j > 0 ? Sb.w[j > 0 ? j - 1 : 0] : 0ull;
+        K[j] = o ? (a << o) | (b >> (64 - o)) : a;
+        KS[j] = o ? (sa << o) | (sb >> (64 - o)) : sa;
+    }
 }
 
 }  // namespace trp

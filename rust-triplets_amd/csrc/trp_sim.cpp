@@ -242,25 +242,31 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                 while (e < rec_end && base[e] != '\n' && base[e] != '\r') e++;
                 pb.clear_marker(p);
                 bool first = true;
-                const u64 w0 = p >> 6, w1 = e > p ? (e - 1) >> 6 : w0;
-                if (w1 - w0 < (u64)G3_WORDS) {   // short line: the bit-mask solver, as in k_plan
-                    G3Bits X, DG, AL;
-                    for (int jw = 0; jw < G3_WORDS; jw++) {
-                        X.w[jw] = DG.w[jw] = AL.w[jw] = 0;
-                        const u64 w = w0 + jw;
-                        if (w > w1) continue;
-                        u64 range = ~0ull;
-                        if (w == w0) range &= ~below((int)(p & 63));
-                        if (w == w1 && (e & 63)) range &= below((int)(e & 63));
-                        X.w[jw] = ~(cls[w].ws | (table ? cls[w].pipe : 0ull)) & range;
-                        DG.w[jw] = cls[w].dig & range;
-                        AL.w[jw] = cls[w].alp & range;
+                if (e > p && e - p <= 64u * G3_WORDS) {   // the bit-mask solvers, as on the device
+                    const u64 w0 = p >> 6;
+                    auto masks = [&](u32 w) -> G3Src {
+                        G3Src r = {0, 0, 0};
+                        const u64 wb = w0 + w;
+                        if (wb < nB) {
+                            r.x = ~(cls[wb].ws | (table ? cls[wb].pipe : 0ull));
+                            r.dg = cls[wb].dig;
+                            r.al = cls[wb].alp;
+                        }
+                        return r;
+                    };
+                    u64 Kw[G3_WORDS + 1] = {0, 0, 0, 0, 0}, KSw[G3_WORDS + 1] = {0, 0, 0, 0, 0};
+                    const u32 s0 = (u32)(p & 63), e0 = (u32)(e - w0 * 64);
+                    if (e - p <= 64u * G3_SHORT) {
+                        u64 K2[G3_SHORT + 1], S2[G3_SHORT + 1];
+                        g3_solve_shifted<G3_SHORT>(masks, s0, e0, cfg.max_digit_ratio, K2, S2);
+                        for (int i = 0; i <= G3_SHORT; i++) { Kw[i] = K2[i]; KSw[i] = S2[i]; }
+                    } else {
+                        g3_solve_shifted<G3_WORDS>(masks, s0, e0, cfg.max_digit_ratio, Kw, KSw);
                     }
-                    const G3Bits Kb = g3_bits_solve(X, DG, AL, cfg.max_digit_ratio);
                     for (u64 q = p; q < e; q++) {
                         const u64 i = q - w0 * 64;
-                        if (!((Kb.w[i >> 6] >> (i & 63)) & 1)) continue;
-                        const bool start = i == 0 || !((Kb.w[(i - 1) >> 6] >> ((i - 1) & 63)) & 1);
+                        if (!((Kw[i >> 6] >> (i & 63)) & 1)) continue;
+                        const bool start = (KSw[i >> 6] >> (i & 63)) & 1;
                         pb.set(q, true, true, start ? (first ? (rab ? 2 : 0) : 1) : 0);
                         if (start) first = false;
                     }
