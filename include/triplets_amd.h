@@ -164,13 +164,35 @@ int trp_materialize_chunk_text_device(trp_ctx* ctx, uint8_t** d_text, uint64_t**
 
 /* "First k tokens" text of every record of the last device-resident batch: the record's preprocessed text
  * verbatim when it has at most max_tokens tokens, otherwise its first max_tokens tokens joined by one
- * space.  This is the truncation rule the reference applies after the path: BM25 query capping
- * (src/sampler/backends/bm25_backend.rs:212-229), record_bm25_text (:503-532, over the text it assembled)
- * and the body of a decorated chunk (src/sampler/mod.rs:1484-1497, with max_tokens = remaining budget).
- * Produces device arrays like trp_materialize_chunk_text_device: text bytes and text_offsets[R+1].
- * (The reference treats a limit of 0 as "no limit" at its call sites; here 0 selects no tokens.) */
+ * space.  With max_tokens = 64 over a batch of query texts this is the BM25 query cap
+ * (src/sampler/backends/bm25_backend.rs:219-225).  Produces device arrays like
+ * trp_materialize_chunk_text_device: text bytes and text_offsets[R+1].  (A limit of 0 selects no tokens; the
+ * reference's "0 = no limit" convention of record_bm25_text is implemented by trp_bm25_texts_device.) */
 int trp_head_tokens_text_device(trp_ctx* ctx, uint32_t max_tokens, uint8_t** d_text,
                                 uint64_t** d_text_offsets, uint64_t* n_text_bytes);
+
+/* The body of decorate_chunk (src/sampler/mod.rs:1484-1506, rng-free twin :1596-1618) for n selected chunks of
+ * the last device-resident batch.  chunk_index[i] (host array) names a chunk of the batch, budget[i] (host
+ * array) the number of body tokens that fit behind the sampled prefix: max_window_tokens - prefix_tokens when
+ * prefix_tokens + body_tokens > max_window_tokens > 0 (:1497-1498), any value >= the chunk's token count
+ * otherwise.  Text i is the chunk's text verbatim when the budget covers it (:1504), else its first budget[i]
+ * tokens joined by one space (:1498-1500); the caller puts prefix + platform_newline() in front (the prefix
+ * is sampled by the host's RNG, src/kvp.rs) and sets tokens_estimate (:1495, :1501, :1505).  Produces device
+ * arrays: text bytes and text_offsets[n+1]. */
+int trp_chunk_bodies_device(trp_ctx* ctx, const uint32_t* chunk_index, const uint32_t* budget, uint64_t n,
+                            uint8_t** d_text, uint64_t** d_text_offsets, uint64_t* n_text_bytes);
+
+/* record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) for n_docs documents over the last
+ * device-resident batch, whose records are the headings and section texts of the documents in order (a None
+ * heading is simply left out of the batch): document i is records [doc_offsets[i], doc_offsets[i+1]) (host
+ * array, n_docs+1 entries).  Text i = every non-blank record followed by `newline` (:505-516; blank = no token,
+ * i.e. trim().is_empty()), cut to its first max_tokens tokens joined by one space when it has more than
+ * max_tokens > 0 of them (:523-531); max_tokens = 0 means no limit (:520-521).  A document without any token
+ * yields the empty text: the caller substitutes the record id (:517-519).  `newline` is platform_newline()
+ * ("\n" or "\r\n").  Produces device arrays: text bytes and text_offsets[n_docs+1]. */
+int trp_bm25_texts_device(trp_ctx* ctx, const uint64_t* doc_offsets, uint64_t n_docs, uint32_t max_tokens,
+                          const char* newline, uint8_t** d_text, uint64_t** d_text_offsets,
+                          uint64_t* n_text_bytes);
 
 /* normalize_inline_whitespace (src/utils.rs:18-33) for every record of a batch: each run of White_Space
  * characters becomes one ' ' and the result is trimmed.  The File and CSV sources apply it to every text

@@ -562,3 +562,102 @@ size_t orc_normalize_inline_whitespace(const uint8_t* text, size_t len, uint8_t*
     free(b.p);
     return r;
 }
+
+/* ---- the steps right after the path -------------------------------------------------------------- */
+
+static void push_joined(buf_t* b, const strvec_t* v, size_t n) {   /* tokens.take(n).join(" ") */
+    for (size_t i = 0; i < n && i < v->n; i++) {
+        if (i) buf_push1(b, ' ');
+        buf_push(b, v->v[i].p, v->v[i].len);
+    }
+}
+
+/* The body of decorate_chunk once a prefix was sampled (src/sampler/mod.rs:1484-1506, the rng-free twin
+ * :1596-1618): the chunk text behind the prefix on its own line, cut to max_window_tokens in all. */
+size_t orc_decorate_chunk(const uint8_t* text, size_t text_len, const uint8_t* prefix, size_t prefix_len,
+                          uint32_t max_window_tokens, const uint8_t* newline, size_t newline_len,
+                          uint8_t** out, uint64_t* tokens_estimate) {
+    str_t body = { text, text_len }, pre = { prefix, prefix_len };
+    strvec_t body_tokens = { 0, 0, 0 }, prefix_tokens = { 0, 0, 0 };
+    split_whitespace(body, &body_tokens);                       /* :1484 */
+    split_whitespace(pre, &prefix_tokens);                      /* :1485 */
+    size_t total_tokens = prefix_tokens.n + body_tokens.n;      /* :1486 */
+    size_t max_window = max_window_tokens;                      /* :1487 */
+    buf_t b = { 0, 0, 0 };
+    if (max_window > 0 && total_tokens > max_window) {          /* :1488 */
+        if (prefix_tokens.n >= max_window) {                    /* :1489 */
+            push_joined(&b, &prefix_tokens, max_window);        /* :1490-1494 */
+            *tokens_estimate = max_window;                      /* :1495 */
+        } else {
+            size_t remaining = max_window - prefix_tokens.n;    /* :1497 */
+            buf_push(&b, prefix, prefix_len);                   /* :1499-1500 */
+            buf_push(&b, newline, newline_len);
+            push_joined(&b, &body_tokens, remaining);
+            *tokens_estimate = max_window;                      /* :1501 */
+        }
+    } else {
+        buf_push(&b, prefix, prefix_len);                       /* :1504 */
+        buf_push(&b, newline, newline_len);
+        buf_push(&b, text, text_len);
+        *tokens_estimate = total_tokens;                        /* :1505 */
+    }
+    free(body_tokens.v);
+    free(prefix_tokens.v);
+    *out = b.p;
+    return b.len;
+}
+
+/* record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532).  The record's sections arrive as 2 * n
+ * strings: heading (has_heading[i] = 0 for None) and text of section i. */
+size_t orc_record_bm25_text(const uint8_t* const* headings, const size_t* heading_len, const uint8_t* has_heading,
+                            const uint8_t* const* texts, const size_t* text_len, size_t n_sections,
+                            const uint8_t* record_id, size_t id_len, size_t max_tokens,
+                            const uint8_t* newline, size_t newline_len, uint8_t** out) {
+    buf_t b = { 0, 0, 0 };
+    for (size_t i = 0; i < n_sections; i++) {                   /* :505 */
+        str_t h = { headings[i], heading_len[i] }, t = { texts[i], text_len[i] };
+        if (has_heading[i] && str_trim(h).len) {                /* :506-507 */
+            buf_push(&b, h.p, h.len);
+            buf_push(&b, newline, newline_len);
+        }
+        if (str_trim(t).len) {                                  /* :512 */
+            buf_push(&b, t.p, t.len);
+            buf_push(&b, newline, newline_len);
+        }
+    }
+    str_t all = { b.p, b.len };
+    if (str_trim(all).len == 0) {                               /* :517-518 */
+        b.len = 0;
+        buf_push(&b, record_id, id_len);
+        *out = b.p;
+        return b.len;
+    }
+    if (max_tokens == 0) { *out = b.p; return b.len; }          /* :520-521 */
+    strvec_t tokens = { 0, 0, 0 };
+    split_whitespace(all, &tokens);                             /* :523 */
+    if (tokens.n <= max_tokens) {                               /* :524-525 */
+        free(tokens.v);
+        *out = b.p;
+        return b.len;
+    }
+    buf_t j = { 0, 0, 0 };
+    push_joined(&j, &tokens, max_tokens);                       /* :527-531 */
+    free(tokens.v);
+    free(b.p);
+    *out = j.p;
+    return j.len;
+}
+
+/* BM25 query capping (bm25_backend.rs:219-225): the text itself when it has at most `limit` tokens, else
+ * its first `limit` tokens joined by one space. */
+size_t orc_cap_tokens(const uint8_t* text, size_t len, size_t limit, uint8_t** out) {
+    str_t s = { text, len };
+    strvec_t tokens = { 0, 0, 0 };
+    split_whitespace(s, &tokens);
+    buf_t b = { 0, 0, 0 };
+    if (tokens.n <= limit) buf_push(&b, text, len);
+    else push_joined(&b, &tokens, limit);
+    free(tokens.v);
+    *out = b.p;
+    return b.len;
+}

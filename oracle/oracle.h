@@ -17,6 +17,8 @@
  *   src/tokenizer.rs:55-65                                       WhitespaceTokenizer
  *   src/chunking/sliding_window.rs:11-117                        SlidingWindowChunker
  *   src/config.rs:34-42, 60-71                                   parameter defaults
+ *   src/sampler/mod.rs:1484-1506                                 decorate_chunk (text after the prefix)
+ *   src/sampler/backends/bm25_backend.rs:219-225, 503-532        BM25 query cap, record_bm25_text
  */
 #ifndef TRP_ORACLE_H
 #define TRP_ORACLE_H
@@ -102,6 +104,20 @@ size_t orc_strip_table_pipes(const uint8_t* line, size_t len, uint8_t* out);
 /* normalize_inline_whitespace (src/utils.rs:18-33): the File/CSV sources apply it before
  * the path; used to restate the example_dataset configuration. */
 size_t orc_normalize_inline_whitespace(const uint8_t* text, size_t len, uint8_t* out);
+
+/* The steps right after the path (they re-use its tokenizer).  Each returns the byte length and stores a
+ * malloc'd buffer in *out (NULL when the length is 0).
+ * orc_decorate_chunk: body of decorate_chunk for a sampled prefix (src/sampler/mod.rs:1484-1506).
+ * orc_record_bm25_text: src/sampler/backends/bm25_backend.rs:503-532.
+ * orc_cap_tokens: the BM25 query cap (bm25_backend.rs:219-225). */
+size_t orc_decorate_chunk(const uint8_t* text, size_t text_len, const uint8_t* prefix, size_t prefix_len,
+                          uint32_t max_window_tokens, const uint8_t* newline, size_t newline_len,
+                          uint8_t** out, uint64_t* tokens_estimate);
+size_t orc_record_bm25_text(const uint8_t* const* headings, const size_t* heading_len, const uint8_t* has_heading,
+                            const uint8_t* const* texts, const size_t* text_len, size_t n_sections,
+                            const uint8_t* record_id, size_t id_len, size_t max_tokens,
+                            const uint8_t* newline, size_t newline_len, uint8_t** out);
+size_t orc_cap_tokens(const uint8_t* text, size_t len, size_t limit, uint8_t** out);
 
 #ifdef __cplusplus
 }

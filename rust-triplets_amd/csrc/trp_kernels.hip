@@ -314,6 +314,32 @@ __device__ inline LaneCarry wave_carry(const WaveLines& W, const J& Pw, const S&
     return k;
 }
 
+// A block's own LineSum in one register (d, a, p <= 64 and f < 32).
+__device__ inline u32 pack_ls(const LineSum& x) { return x.d | (x.a << 8) | (x.p << 16) | (x.f << 24); }
+__device__ inline LineSum unpack_ls8(u32 v) {
+    LineSum r = {v & 0xFFu, (v >> 8) & 0xFFu, (v >> 16) & 0xFFu, v >> 24};
+    return r;
+}
+// A summary that is the same in every lane (read from LDS at a uniform address), moved to scalar registers.
+__device__ inline u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline LineSum uniform_ls(const LineSum& x) {
+    LineSum r = {uni(x.d), uni(x.a), uni(x.p), uni(x.f)};
+    return r;
+}
+__device__ inline J uniform_J(const J& j) {
+    J r;
+    r.head = uniform_ls(j.head);
+    r.tail = uniform_ls(j.tail);
+    r.g = uni(j.g);
+    return r;
+}
+__device__ inline S uniform_S(const S& x) {
+    S r;
+    r.head = uniform_ls(x.head);
+    r.has_ls = uni(x.has_ls);
+    return r;
+}
+
 struct JOp { __device__ J operator()(const J& a, const J& b) const { return j_combine(a, b); } };
 struct SOp { __device__ S operator()(const S& a, const S& b) const { return s_combine(a, b); } };
 
@@ -949,28 +975,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
     LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w[tid], sh.rs.w[tid + 1], NORMALIZE);
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
-    const WaveLines W = wave_lines(lane_J(L.c, L.d));
+    const J own = lane_J(L.c, L.d);
+    // the block's own head / tail statistics are used again by plan_block: parked in one register each
+    const u32 own_head = pack_ls(own.head), own_tail = pack_ls(own.tail);
+    const WaveLines W = wave_lines(own);
     {
         const J wt = wave_total(W);
         if (lane == 0) sh.jscan[wave] = wt;
     }
     __syncthreads();   // also: every lane has classified its block, the byte image is free from here on
-    // what enters this wave from the left and from the right: folds over the other waves' totals, written
-    // out for the four waves and selected field by field (keeps the summaries in registers)
-    J Pw = sh.seed_j;
-    S Xw = sh.seed_s;
+    // what enters this wave from the left and from the right: folds over the other waves' totals.  The
+    // summaries are the same for every lane: moved to scalar registers, so that the folds run on the scalar unit
+    J Pw = uniform_J(sh.seed_j);
+    S Xw = uniform_S(sh.seed_s);
     {
         const int wu = __builtin_amdgcn_readfirstlane(wave);   // scalar: the branches below are uniform
 #pragma unroll
         for (int w = 0; w < NT / 64 - 1; w++) {
-            if (w < wu) Pw = j_combine(Pw, sh.jscan[w]);
+            if (w < wu) Pw = j_combine(Pw, uniform_J(sh.jscan[w]));
             const int v = NT / 64 - 1 - w;
-            if (v > wu) Xw = s_combine(s_from_J(sh.jscan[v]), Xw);
+            if (v > wu) Xw = s_combine(uniform_S(s_from_J(sh.jscan[v])), Xw);
         }
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
-    Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp) : plan_block(L.c, L.d, k, cfg);
+    Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
+                        : plan_block(L.c, L.d, k, cfg, unpack_ls8(own_head), unpack_ls8(own_tail));
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -1842,6 +1872,80 @@ __global__ __launch_bounds__(NT) void k_chunk_text_emit(const ChunkDesc* __restr
     }
 }
 
+// Body of a decorated chunk (src/sampler/mod.rs:1484-1506): descriptor i is chunk index[i] of the batch cut to
+// its first budget[i] tokens (unchanged when the budget covers it, which keeps the verbatim rendering of a
+// record's only window).
+__global__ void k_body_desc(const ChunkDesc* __restrict__ chunks, u64 C, const u32* __restrict__ index,
+                            const u32* __restrict__ budget, u64 n, ChunkDesc* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ChunkDesc z = {0, 0, 0, 0, 0, 0, 0, 0};
+    ChunkDesc d = index[i] < C ? chunks[index[i]] : z;
+    const u32 have = d.tok_end - d.tok_begin;
+    if (budget[i] < have) d.tok_end = d.tok_begin + budget[i];
+    out[i] = d;
+}
+
+// record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) over the records of the batch: document i is
+// the concatenation of records [doc_off[i], doc_off[i+1]) (headings and section texts in order).  A record
+// without a token is blank (`trim().is_empty()`) and left out; the others are followed by the newline.  With
+// more than max_tokens tokens (max_tokens > 0) the document is its first max_tokens tokens joined by one
+// space; the tokens of a document are consecutive in the token table.  A document without any token has
+// length 0 (the caller substitutes the record id).  One wavefront per document.
+__global__ __launch_bounds__(NT) void k_doc_text(const u64* __restrict__ doc_off, u64 D, u32 max_tokens, u32 nl_len,
+                                                  u32 nl_bytes, const u64* __restrict__ tok_off,
+                                                  const u64* __restrict__ den_off, const u32* __restrict__ tok_start,
+                                                  const u32* __restrict__ tok_len, const u8* __restrict__ denoised,
+                                                  u64* __restrict__ lens, const u64* __restrict__ text_off,
+                                                  u8* __restrict__ text) {
+    const int lane = threadIdx.x & 63;
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= D) return;
+    const u64 r0 = doc_off[i], r1 = doc_off[i + 1];
+    const u64 t0 = tok_off[r0], T = tok_off[r1] - t0;
+    u8* dst = text ? text + text_off[i] : nullptr;   // first call: lengths only
+    if (T == 0) {
+        if (!text && lane == 0) lens[i] = 0;
+        return;
+    }
+    if (max_tokens == 0 || T <= (u64)max_tokens) {
+        u64 at = 0;
+        for (u64 r = r0; r < r1; r++) {   // uniform
+            if (tok_off[r + 1] == tok_off[r]) continue;
+            const u64 n = den_off[r + 1] - den_off[r];
+            if (dst) {
+                const u8* src = denoised + den_off[r];
+                for (u64 k = lane; k < n; k += 64) dst[at + k] = src[k];
+                if (lane < (int)nl_len) dst[at + n + lane] = (u8)(nl_bytes >> (8 * lane));
+            }
+            at += n + nl_len;
+        }
+        if (!text && lane == 0) lens[i] = at;
+        return;
+    }
+    u64 base = 0;
+    for (u32 k0 = 0; k0 < max_tokens; k0 += 64) {
+        const u32 k = k0 + (u32)lane;
+        const bool have = k < max_tokens;
+        const u64 len = have ? tok_len[t0 + k] : 0;
+        const u64 span = have ? len + (k + 1 < max_tokens ? 1 : 0) : 0;   // token plus its trailing space
+        u64 inc = span;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (have && dst) {
+            u8* d = dst + base + inc - span;
+            const u8* sp = denoised + tok_start[t0 + k];
+            for (u64 q = 0; q < len; q++) d[q] = sp[q];
+            if (span > len) d[len] = ' ';
+        }
+        base += __shfl(inc, 63, 64);
+    }
+    if (!text && lane == 0) lens[i] = base;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1881,7 +1985,8 @@ struct trp_ctx {
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
     DevBuf far_list;                    // tiles whose carries need a long walk (k_tile_carry)
-    DevBuf heads;                       // head-of-record descriptors (trp_head_tokens_text_device)
+    DevBuf heads;                       // head-of-record / chunk-body descriptors (trp_head_tokens_text_device, trp_chunk_bodies_device)
+    DevBuf sel;                         // caller's selection arrays (chunk indices + budgets, document offsets)
     u64* h_totals = nullptr;            // pinned
     bool profiling = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
@@ -2044,7 +2149,7 @@ void trp_destroy(trp_ctx* c) {
                       &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
-                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list};
+                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list, &c->sel};
     for (DevBuf* b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -2341,6 +2446,71 @@ int trp_head_tokens_text_device(trp_ctx* c, uint32_t max_tokens, uint8_t** d_tex
     if (R) hipLaunchKernelGGL(k_head_desc, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, c->last.tok_offsets, R,
                               max_tokens, c->heads.as<ChunkDesc>());
     return render_text(c, c->heads.as<ChunkDesc>(), R, (const u64*)nullptr, d_text, d_text_offsets, n_text_bytes);
+}
+
+int trp_chunk_bodies_device(trp_ctx* c, const uint32_t* chunk_index, const uint32_t* budget, uint64_t n,
+                            uint8_t** d_text, uint64_t** d_text_offsets, uint64_t* n_text_bytes) {
+    if (!c || !d_text || !d_text_offsets || !n_text_bytes || (n && (!chunk_index || !budget)))
+        return fail(TRP_E_ARG, "null argument");
+    if (!c->have_last) return fail(TRP_E_ARG, "no device batch result to render");
+    HIPCHK(hipSetDevice(c->device));
+    const trp_result& L = c->last;
+    for (uint64_t i = 0; i < n; i++)
+        if (chunk_index[i] >= L.n_chunks) return fail(TRP_E_ARG, "chunk index out of range");
+    int rc;
+    if ((rc = c->heads.ensure((n + 1) * sizeof(ChunkDesc)))) return rc;
+    if ((rc = c->sel.ensure((2 * n + 2) * sizeof(u32)))) return rc;
+    u32* d_idx = c->sel.as<u32>();
+    u32* d_bud = d_idx + n;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(d_idx, chunk_index, n * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_bud, budget, n * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_body_desc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const ChunkDesc*>(L.chunks), L.n_chunks, d_idx, d_bud, n, c->heads.as<ChunkDesc>());
+        HIPCHK(hipStreamSynchronize(c->stream));   // the index arrays are the caller's (pageable) memory
+    }
+    return render_text(c, c->heads.as<ChunkDesc>(), n, L.chunk_offsets, d_text, d_text_offsets, n_text_bytes);
+}
+
+int trp_bm25_texts_device(trp_ctx* c, const uint64_t* doc_offsets, uint64_t n_docs, uint32_t max_tokens,
+                          const char* newline, uint8_t** d_text, uint64_t** d_text_offsets, uint64_t* n_text_bytes) {
+    if (!c || !d_text || !d_text_offsets || !n_text_bytes || !doc_offsets || !newline)
+        return fail(TRP_E_ARG, "null argument");
+    if (!c->have_last) return fail(TRP_E_ARG, "no device batch result to render");
+    const size_t nl_len = strlen(newline);
+    if (nl_len > 4) return fail(TRP_E_ARG, "newline longer than 4 bytes");
+    const u64 R = c->last_R;
+    for (uint64_t i = 0; i < n_docs; i++)
+        if (doc_offsets[i] > doc_offsets[i + 1] || doc_offsets[i + 1] > R)
+            return fail(TRP_E_ARG, "document offsets must be non-decreasing record indices of the last batch");
+    HIPCHK(hipSetDevice(c->device));
+    u32 nl_bytes = 0;
+    for (size_t i = 0; i < nl_len; i++) nl_bytes |= (u32)(u8)newline[i] << (8 * i);
+    const trp_result& L = c->last;
+    int rc;
+    if ((rc = c->sel.ensure((n_docs + 1) * sizeof(u64)))) return rc;
+    if ((rc = c->text_len.ensure((n_docs + 1) * sizeof(u64)))) return rc;
+    if ((rc = c->text_off.ensure((n_docs + 2) * sizeof(u64)))) return rc;
+    u64* d_doc = c->sel.as<u64>();
+    HIPCHK(hipMemcpyAsync(d_doc, doc_offsets, (n_docs + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)((n_docs * 64 + NT - 1) / NT));
+    if (n_docs) hipLaunchKernelGGL(k_doc_text, grid, dim3(NT), 0, c->stream, d_doc, n_docs, max_tokens, (u32)nl_len, nl_bytes,
+                                   L.tok_offsets, L.denoised_offsets, L.tok_start, L.tok_len, L.denoised,
+                                   c->text_len.as<u64>(), (const u64*)nullptr, (u8*)nullptr);
+    if ((rc = scan_u64(c, c->text_len.as<u64>(), n_docs, c->text_off.as<u64>()))) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->text_off.as<u64>() + n_docs, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const u64 nbytes = c->h_totals[4];
+    if ((rc = c->text.ensure(nbytes + 16))) return rc;
+    if (n_docs) hipLaunchKernelGGL(k_doc_text, grid, dim3(NT), 0, c->stream, d_doc, n_docs, max_tokens, (u32)nl_len, nl_bytes,
+                                   L.tok_offsets, L.denoised_offsets, L.tok_start, L.tok_len, L.denoised,
+                                   (u64*)nullptr, c->text_off.as<u64>(), c->text.as<u8>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *d_text = c->text.as<u8>();
+    *d_text_offsets = c->text_off.as<u64>();
+    *n_text_bytes = nbytes;
+    return TRP_OK;
 }
 
 static DevCfg normalize_devcfg() {

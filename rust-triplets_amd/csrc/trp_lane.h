@@ -807,7 +807,10 @@ TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
     return k;
 }
 
-TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg) {
+// own_head / own_tail: the block's own statistics before its first and from its last line start on, as
+// lane_J computes them (head and tail of the block's summary).
+TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg, const LineSum& own_head,
+                       const LineSum& own_tail) {
     Plan out = {0, 0, 0, 0};
     const bool head0 = !(d.LS & 1ull);      // the block starts inside a line begun earlier
     // Cell trimming of table rows (strip_table_pipes): a whitespace byte survives only when the
@@ -832,59 +835,69 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         CS = T & ~prevtext;                 // first byte of a trimmed cell
         have_table_masks = true;
     };
-
-    // One iteration per line that touches the block: the line that runs into it (bit 0 stands for it) and the
-    // lines that start in it, without the empty ones (a line start that sits on its own terminator: nothing
-    // of such a line is ever emitted).
-    u64 todo = (d.LS & ~(d.TERM | d.DEL)) | (head0 ? 1ull : 0ull);
-    while (todo) {
-        const int s = ctz(todo);
-        todo &= todo - 1;
-        const bool is_head = head0 && s == 0;
-        const u64 nxt = d.LS & ~below(s + 1);
-        const int e = nxt ? ctz(nxt) : 64;
-        const u64 R = below(e) & ~below(s) & d.V;
-        LineSum tot = range_sum(c, d, R);
-        if (is_head) tot = ls_add(k.ci, tot);
-        if (!nxt) tot = ls_add(tot, k.co);
-        if (tot.a > 0) {
-            bool rab;
-            if (is_head) rab = k.ci_rab;
-            else {
-                u64 rsb = d.RS & below(s + 1);
-                if (rsb) rab = (c.alp & below(s) & ~below(top(rsb))) != 0;
-                else rab = k.ar_in || (c.alp & below(s)) != 0;
+    // One line of the block: bytes [s, e) of it, `tot` the statistics of the whole line.
+    auto line = [&](int s, u64 R, bool is_head, const LineSum& tot) {
+        if (tot.a == 0) return;             // gate 2: no alphabetic character, the line is dropped
+        bool rab;
+        if (is_head) rab = k.ci_rab;
+        else {
+            u64 rsb = d.RS & below(s + 1);
+            if (rsb) rab = (c.alp & below(s) & ~below(top(rsb))) != 0;
+            else rab = k.ar_in || (c.alp & below(s)) != 0;
+        }
+        bool table = cfg.strip_markdown && ls_first(tot) == 1u && tot.p >= 2u;
+        bool g3 = ratio_exceeds(tot.d, tot.a, cfg.max_digit_ratio);
+        if (g3) {
+            if (!is_head) {
+                out.TOK |= bit(s);
+                if (table) out.PSP |= bit(s);
+                if (rab) out.PNL |= bit(s);
             }
-            bool table = cfg.strip_markdown && ls_first(tot) == 1u && tot.p >= 2u;
-            bool g3 = ratio_exceeds(tot.d, tot.a, cfg.max_digit_ratio);
-            if (g3) {
-                if (!is_head) {
-                    out.TOK |= bit(s);
-                    if (table) out.PSP |= bit(s);
-                    if (rab) out.PNL |= bit(s);
-                }
-            } else if (!table) {
-                out.C |= d.LC & R;
-                out.TOK |= d.LC & R & ~c.ws;
-                if (!is_head && rab) out.PNL |= bit(s);
-            } else {
-                if (!have_table_masks) table_masks();
-                out.C |= R & (T | IW);
-                out.TOK |= R & T;
-                u64 cs = CS & R, Tr = T & R;
-                if (Tr) {
-                    u64 first = Tr & (~Tr + 1ull);
-                    if (is_head && ls_seen_text(k.ci)) out.PSP |= cs;
-                    else {
-                        out.PSP |= cs & ~first;
-                        if (rab && (cs & first)) out.PNL |= first;
-                    }
+        } else if (!table) {
+            out.C |= d.LC & R;
+            out.TOK |= d.LC & R & ~c.ws;
+            if (!is_head && rab) out.PNL |= bit(s);
+        } else {
+            if (!have_table_masks) table_masks();
+            out.C |= R & (T | IW);
+            out.TOK |= R & T;
+            u64 cs = CS & R, Tr = T & R;
+            if (Tr) {
+                u64 first = Tr & (~Tr + 1ull);
+                if (is_head && ls_seen_text(k.ci)) out.PSP |= cs;
+                else {
+                    out.PSP |= cs & ~first;
+                    if (rab && (cs & first)) out.PNL |= first;
                 }
             }
         }
+    };
+    // The line that runs into the block and the block's last line take their own part from the block's
+    // summary; the lines in between (they start and end inside the block) are counted here.  Empty lines (a
+    // line start that sits on its own terminator) are skipped: nothing of them is ever emitted.
+    const bool has_ls = d.LS != 0;
+    const int first_ls = has_ls ? ctz(d.LS) : 64, last_ls = has_ls ? top(d.LS) : 0;
+    const u64 empty = d.TERM | d.DEL;
+    if (head0) {
+        LineSum tot = ls_add(k.ci, own_head);
+        if (!has_ls) tot = ls_add(tot, k.co);
+        line(0, below(first_ls) & d.V, true, tot);
+    }
+    if (has_ls && !((empty >> last_ls) & 1ull))
+        line(last_ls, ~below(last_ls) & d.V, false, ls_add(own_tail, k.co));
+    u64 todo = has_ls ? (d.LS & ~empty & ~bit(last_ls)) : 0ull;
+    while (todo) {
+        const int s = ctz(todo);
+        todo &= todo - 1;
+        const u64 R = below(ctz(d.LS & ~below(s + 1))) & ~below(s);   // a later line start exists
+        line(s, R, false, range_sum(c, d, R));
     }
     plan_fold_prefixes(out, c.sp, c.nl, d.V);
     return out;
+}
+TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg) {
+    const J own = lane_J(c, d);
+    return plan_block(c, d, k, cfg, own.head, own.tail);
 }
 
 // Plan of the pass-through configuration (denoiser disabled): every byte is "copied" in place and

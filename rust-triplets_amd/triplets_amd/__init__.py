@@ -63,7 +63,7 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
            "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
-           "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event"]
+           "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event", "trp_chunk_bodies_device", "trp_bm25_texts_device"]
 
 _lib = None
 
@@ -114,6 +114,10 @@ def load_library():
     L.trp_get_profile.argtypes = [C.c_void_p, C.POINTER(_KernelTime), C.c_int]
     L.trp_head_tokens_text_device.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.trp_chunk_bodies_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.trp_bm25_texts_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.trp_normalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Result)]
     L.trp_normalize_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                              C.POINTER(_Result)]
@@ -421,6 +425,35 @@ class Context:
         _check(self._L.trp_head_tokens_text_device(self._h, int(max_tokens), C.byref(t), C.byref(o), C.byref(n)))
         return t.value or 0, o.value or 0, int(n.value)
 
+    def _texts_to_host(self, t, o, nbytes, n) -> List[bytes]:
+        """Device text bytes + offsets[n+1] -> list of n byte strings."""
+        offs = np.empty(n + 1, dtype=np.uint64)
+        text = np.empty(nbytes, dtype=np.uint8)
+        _check(self._L.trp_copy_to_host(self._h, offs.ctypes.data, o, offs.nbytes))
+        if nbytes:
+            _check(self._L.trp_copy_to_host(self._h, text.ctypes.data, t, text.nbytes))
+        return [text[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+
+    def chunk_bodies(self, chunk_index: Sequence[int], budget: Sequence[int]) -> List[bytes]:
+        """Text of the selected chunks of the last device batch cut to budget[i] tokens (verbatim when the
+        budget covers the chunk): the body of a decorated chunk, src/sampler/mod.rs:1497-1504."""
+        idx = np.ascontiguousarray(chunk_index, dtype=np.uint32)
+        bud = np.ascontiguousarray(budget, dtype=np.uint32)
+        t, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.trp_chunk_bodies_device(self._h, idx.ctypes.data, bud.ctypes.data, len(idx), C.byref(t),
+                                               C.byref(o), C.byref(n)))
+        return self._texts_to_host(t.value or 0, o.value or 0, int(n.value), len(idx))
+
+    def bm25_texts(self, doc_offsets: Sequence[int], max_tokens: int, newline: str = "\n") -> List[bytes]:
+        """record_bm25_text (bm25_backend.rs:503-532) of the documents whose parts (headings and section texts,
+        in order) are records [doc_offsets[i], doc_offsets[i+1]) of the last device batch.  A document
+        without any token comes back empty: substitute the record id."""
+        do = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        t, o, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(self._L.trp_bm25_texts_device(self._h, do.ctypes.data, len(do) - 1, int(max_tokens),
+                                             newline.encode(), C.byref(t), C.byref(o), C.byref(n)))
+        return self._texts_to_host(t.value or 0, o.value or 0, int(n.value), len(do) - 1)
+
     def set_profiling(self, on: bool):
         _check(self._L.trp_set_profiling(self._h, int(on)))
 
@@ -557,3 +590,68 @@ class SlidingWindowChunker:
             out.append(RecordChunk(record_id, section_idx, view, res.chunk_text(i).decode("utf-8"),
                                    int(c["tok_end"]) - int(c["tok_begin"])))
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# the steps right after the path, on its token table
+# ---------------------------------------------------------------------------------------------------
+def decorate_chunks(ctx: Context, chunks: np.ndarray, chunk_index: Sequence[int], prefixes: Sequence[bytes],
+                    max_window_tokens: int, newline: bytes = b"\n", prefix_ctx: Context = None):
+    """decorate_chunk (src/sampler/mod.rs:1470-1508) for selected chunks of ctx's last device batch, each with
+    the prefix the host's KvpPrefixSampler produced for it: returns [(text, tokens_estimate)].
+    `chunks` is the batch's chunk descriptor array on the host.  The prefixes are tokenised on the GPU as a
+    batch of their own (on prefix_ctx, so that ctx keeps its batch); the bodies are cut on the GPU."""
+    own = prefix_ctx is None
+    pctx = prefix_ctx or Context(0)
+    try:
+        pdata, poffs = pack(list(prefixes))
+        pres = pctx.preprocess_batch(pdata, poffs, DenoiserConfig(False), ChunkingStrategy())
+    finally:
+        if own:
+            pctx.close()
+    n = len(prefixes)
+    np_tok = np.diff(pres.tok_offsets.astype(np.int64))
+    sel = chunks[np.asarray(chunk_index, dtype=np.int64)]
+    nb_tok = sel["tok_end"].astype(np.int64) - sel["tok_begin"].astype(np.int64)
+    total = np_tok + nb_tok
+    mw = int(max_window_tokens)
+    cut = (total > mw) if mw > 0 else np.zeros(n, dtype=bool)          # mod.rs:1488
+    prefix_only = cut & (np_tok >= mw)                                  # :1489
+    budget = np.where(cut & ~prefix_only, mw - np_tok, 0xFFFFFFFF)      # :1497
+    budget = np.where(prefix_only, 0, budget)
+    bodies = ctx.chunk_bodies(chunk_index, budget.astype(np.uint32))
+    out = []
+    for i in range(n):
+        if prefix_only[i]:
+            out.append((b" ".join(pres.tokens(i)[:mw]), mw))            # :1490-1495
+        elif cut[i]:
+            out.append((bytes(prefixes[i]) + newline + bodies[i], mw))  # :1499-1501
+        else:
+            out.append((bytes(prefixes[i]) + newline + bodies[i], int(total[i])))   # :1504-1505
+    return out
+
+
+def record_bm25_texts(records, max_tokens: int, newline: str = "\n", ctx: Context = None) -> List[bytes]:
+    """record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) for many records at once.
+    records: [(record_id, [(heading or None, text), ...]), ...] with byte strings."""
+    import torch
+    ctx = ctx or default_context()
+    parts, doc_offsets = [], [0]
+    for _, sections in records:
+        for heading, text in sections:
+            if heading is not None:
+                parts.append(heading)
+            parts.append(text)
+        doc_offsets.append(len(parts))
+    data, offs = pack(parts)
+    stream = torch.cuda.current_stream().cuda_stream
+    own = Context(0, stream=stream)
+    try:
+        db = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).cuda()
+        do = torch.from_numpy(offs.astype(np.int64)).cuda()
+        own.preprocess_batch_device(db.data_ptr(), do.data_ptr(), len(parts), len(data), DenoiserConfig(False),
+                                    ChunkingStrategy())
+        texts = own.bm25_texts(doc_offsets, max_tokens, newline)
+    finally:
+        own.close()
+    return [t if t else rid for t, (rid, _) in zip(texts, records)]       # :517-519

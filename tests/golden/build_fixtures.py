@@ -272,6 +272,34 @@ EXAMPLE_DATASET = {
 }
 
 
+# The steps right after the path (they re-use its tokenizer): inputs of the reference's own tests and what
+# those tests assert.  The prefix strings are what KvpPrefixSampler renders for the variants the tests add
+# ("meta: key=value", src/kvp.rs:216, :230); `newline` is platform_newline() on Unix.
+BM25 = "src/sampler/backends/bm25_backend.rs"
+AFTER_PATH = {
+    "decorate": [
+        {"ref": SMP + ":566", "text": "one two three", "prefix": "meta: long=a b c d e f g h i",
+         "max_window_tokens": 5, "newline": "\n",
+         "asserted": {"tokens_before": 3, "tokens_after": 5, "tokens_estimate": 5}},
+        {"ref": SMP + ":600", "text": "one two three", "prefix": "meta: source=unit",
+         "max_window_tokens": 4, "newline": "\n",
+         "asserted": {"starts_with": "meta: source=unit\n", "tokens_estimate": 4}},
+    ],
+    "record_bm25_text": [
+        {"ref": SMP + ":10700", "id": "bm25_text_zero",
+         "sections": [["Heading", "anchor body text with many tokens here and there and everywhere"],
+                      [None, "context section body words more and more content"]],
+         "newline": "\n",
+         "asserted": [{"max_tokens": 0, "tokens_more_than": 5, "contains": "Heading"},
+                      {"max_tokens": 5, "tokens": 5}]},
+    ],
+    "query_cap": [
+        {"ref": SMP + ":10637", "limit_ref": "src/constants.rs:154", "limit": 64,
+         "text": " ".join("word%d" % i for i in range(74)), "asserted": {"tokens_before": 74}},
+    ],
+}
+
+
 def main():
     den = {
         "source": DEN,
@@ -289,7 +317,7 @@ def main():
     chk = {"cases": CHUNK}
     ex = {"files": EXAMPLE_DATASET}
     for name, obj in (("denoiser.json", den), ("tokenizer.json", tok), ("chunker.json", chk),
-                      ("example_dataset.json", ex)):
+                      ("example_dataset.json", ex), ("after_path.json", AFTER_PATH)):
         with open(os.path.join(HERE, name), "w", encoding="utf-8") as f:
             json.dump(obj, f, ensure_ascii=False, indent=1)
             f.write("\n")

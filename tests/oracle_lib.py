@@ -64,6 +64,15 @@ def lib():
         L.orc_strip_table_pipes.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_normalize_inline_whitespace.restype = C.c_size_t
         L.orc_normalize_inline_whitespace.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.orc_decorate_chunk.restype = C.c_size_t
+        L.orc_decorate_chunk.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint32, C.c_char_p,
+                                         C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.orc_record_bm25_text.restype = C.c_size_t
+        L.orc_record_bm25_text.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p,
+                                           C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_char_p,
+                                           C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.orc_cap_tokens.restype = C.c_size_t
+        L.orc_cap_tokens.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
@@ -177,3 +186,38 @@ def batch(data: np.ndarray, offsets: np.ndarray, cfg, n_threads=1) -> BatchResul
         n_chunks=int(res.n_chunks))
     L.orc_result_free(C.byref(res))
     return out
+
+
+def _take(ptr, n):
+    out = C.string_at(ptr, n) if n else b""
+    if ptr:
+        lib().free(ptr)
+    return out
+
+
+def decorate_chunk(text: bytes, prefix: bytes, max_window_tokens: int, newline: bytes = b"\n"):
+    """decorate_chunk's text and tokens_estimate for a sampled prefix (src/sampler/mod.rs:1484-1506)."""
+    out, est = C.c_void_p(), C.c_uint64()
+    n = lib().orc_decorate_chunk(text, len(text), prefix, len(prefix), max_window_tokens, newline, len(newline),
+                                 C.byref(out), C.byref(est))
+    return _take(out, n), int(est.value)
+
+
+def record_bm25_text(record_id: bytes, sections, max_tokens: int, newline: bytes = b"\n") -> bytes:
+    """record_bm25_text (bm25_backend.rs:503-532); sections = [(heading or None, text), ...]."""
+    n = len(sections)
+    hs = (C.c_char_p * max(1, n))(*[h if h is not None else b"" for h, _ in sections])
+    hl = (C.c_size_t * max(1, n))(*[len(h) if h is not None else 0 for h, _ in sections])
+    has = bytes(1 if h is not None else 0 for h, _ in sections) + b"\0"
+    ts = (C.c_char_p * max(1, n))(*[t for _, t in sections])
+    tl = (C.c_size_t * max(1, n))(*[len(t) for _, t in sections])
+    out = C.c_void_p()
+    ln = lib().orc_record_bm25_text(hs, hl, has, ts, tl, n, record_id, len(record_id), max_tokens, newline,
+                                    len(newline), C.byref(out))
+    return _take(out, ln)
+
+
+def cap_tokens(text: bytes, limit: int) -> bytes:
+    out = C.c_void_p()
+    n = lib().orc_cap_tokens(text, len(text), limit, C.byref(out))
+    return _take(out, n)

@@ -11,7 +11,7 @@ rows=defaultdict(lambda: defaultdict(dict))
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
-        for k in ("k_plan","k_emit","k_seed"):
+        for k in ("k_plan<","k_emit<","k_seed<"):
             if k in n:
                 d=rows[k][int(r["Dispatch_Id"])]
                 d[r["Counter_Name"]]=d.get(r["Counter_Name"],0)+float(r["Counter_Value"])

@@ -11,7 +11,7 @@ from collections import defaultdict
 rows=defaultdict(dict)
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_emit" in r["Kernel_Name"]:
+        if "k_emit<" in r["Kernel_Name"]:
             d=rows[int(r["Dispatch_Id"])]
             d[r["Counter_Name"]]=d.get(r["Counter_Name"],0)+float(r["Counter_Value"])
 last=rows[max(rows)]   # the profiled (phase-stopped) dispatches come last
