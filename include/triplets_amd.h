@@ -125,6 +125,27 @@ int trp_wait_event(trp_ctx* ctx, void* hip_event);
 int trp_preprocess_batch(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets,
                          uint64_t n_records, const trp_config* cfg, trp_result* out);
 void trp_result_free(trp_result* r);
+/* The same call for consumers that do not need every array back: `outputs` selects what is copied to the
+ * host (the link from the GPU is the limit of this entry point: all arrays together are about 2.4 bytes per
+ * input byte).  The per-record arrays (the three offset arrays, dropped[]) and the totals always come back;
+ * an array that was not selected is NULL in `out`.  TRP_OUT_CHUNK_TEXT renders every chunk's text on the GPU
+ * (RecordChunk::text, sliding_window.rs:44, :67, :95-100) and returns it in `chunk_text`: what a sampler
+ * that serves ChunkingAlgorithm::materialize from a table needs is chunks + chunk text, without the
+ * preprocessed text and the token table.  Release with trp_result_free and trp_chunk_text_free. */
+#define TRP_OUT_TEXT 1u       /* denoised */
+#define TRP_OUT_TOKENS 2u     /* tok_start, tok_len */
+#define TRP_OUT_CHUNKS 4u     /* chunks */
+#define TRP_OUT_CHUNK_TEXT 8u /* chunk_text (must be non-NULL) */
+#define TRP_OUT_ALL 7u        /* what trp_preprocess_batch returns */
+typedef struct {
+    uint8_t* text;     /* text of all chunks, concatenated in chunk order */
+    uint64_t* offsets; /* n_chunks + 1 */
+    uint64_t n_bytes;
+} trp_chunk_text;
+int trp_preprocess_batch_select(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets,
+                                uint64_t n_records, const trp_config* cfg, uint32_t outputs, trp_result* out,
+                                trp_chunk_text* chunk_text);
+void trp_chunk_text_free(trp_chunk_text* t);
 /* Large host result arrays are page-locked blocks that trp_result_free / trp_free return to a
  * process-wide pool for the next call (up to 16 GiB stays pooled).  trp_trim_host_pool unpins and frees
  * the blocks that are not in use.  No counterpart in the reference (its results are heap Strings). */

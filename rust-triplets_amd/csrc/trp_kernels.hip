@@ -2651,7 +2651,7 @@ constexpr u64 PIPE_SUB_BYTES = 96ull << 20;
 constexpr u64 PIPE_MIN_BYTES = 256ull << 20;
 
 static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
-                              trp_result* out) {
+                              uint32_t outputs, trp_result* out, trp_chunk_text* ctext) {
     const u64 N = offsets[R];
     int rc;
     if (!c->aux && (rc = trp_create(c->device, &c->aux))) return rc;
@@ -2687,12 +2687,15 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
 
     memset(out, 0, sizeof(*out));
     HostPool& hp = host_pool();
-    u64 cap_den = 0, cap_tok = 0, cap_ch = 0;          // capacities of the three data-dependent arrays
-    u64 base_d = 0, base_t = 0, base_c = 0;
+    const bool want_den = outputs & TRP_OUT_TEXT, want_tok = outputs & TRP_OUT_TOKENS, want_ch = outputs & TRP_OUT_CHUNKS,
+               want_ct = (outputs & TRP_OUT_CHUNK_TEXT) && ctext;
+    u64 cap_den = 0, cap_tok = 0, cap_ch = 0, cap_ct = 0, cap_cto = 0;   // capacities of the data-dependent arrays
+    u64 base_d = 0, base_t = 0, base_c = 0, base_x = 0;
     // on failure: copies into the result arrays may still be in flight on either stream
     auto fail_free = [&](int code) {
         for (trp_ctx* x : cx) (void)hipStreamSynchronize(x->stream);
         trp_result_free(out);
+        if (ctext) { hp.release(ctext->text); hp.release(ctext->offsets); memset(ctext, 0, sizeof(*ctext)); }
         return code;
     };
     auto sync_all = [&]() -> int {
@@ -2727,29 +2730,45 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
         if (i + 1 < S && (rc = send(i + 1))) return fail_free(rc);
         trp_result d;
         if ((rc = run_device(x, x->in_bytes.as<u8>(), x->in_offsets.as<u64>(), Rs, Ns, dc, &d))) return fail_free(rc);
+        // chunk text is rendered on the device from this sub-batch's own arrays, before they are shifted
+        uint8_t* d_ct = nullptr;
+        uint64_t* d_cto = nullptr;
+        uint64_t n_ct = 0;
+        if (want_ct && (rc = render_text(x, reinterpret_cast<const ChunkDesc*>(d.chunks), d.n_chunks, d.chunk_offsets, &d_ct,
+                                         &d_cto, &n_ct))) return fail_free(rc);
         if (i == 0) {   // size the result arrays from the first sub-batch's yield, with a margin
             const double scale = Ns ? (double)N / (double)Ns * 1.08 : 1.0;
             u64 want_d = std::min<u64>(N + 64, (u64)((double)d.n_denoised * scale) + (1u << 20));
-            if ((rc = grow((void**)&out->denoised, &cap_den, S == 1 ? d.n_denoised : want_d, 0, 1))) return fail_free(rc);
+            if (want_den && (rc = grow((void**)&out->denoised, &cap_den, S == 1 ? d.n_denoised : want_d, 0, 1))) return fail_free(rc);
             u64 want_t = (u64)((double)d.n_tokens * scale) + (1u << 18);
             u64 tcap = 0;
-            if ((rc = grow((void**)&out->tok_start, &tcap, S == 1 ? d.n_tokens : want_t, 0, sizeof(u32)))) return fail_free(rc);
-            if ((rc = grow((void**)&out->tok_len, &cap_tok, S == 1 ? d.n_tokens : want_t, 0, sizeof(u32)))) return fail_free(rc);
+            if (want_tok && (rc = grow((void**)&out->tok_start, &tcap, S == 1 ? d.n_tokens : want_t, 0, sizeof(u32)))) return fail_free(rc);
+            if (want_tok && (rc = grow((void**)&out->tok_len, &cap_tok, S == 1 ? d.n_tokens : want_t, 0, sizeof(u32)))) return fail_free(rc);
             u64 want_c = (u64)((double)d.n_chunks * scale) + R / 8 + 4096;
-            if ((rc = grow((void**)&out->chunks, &cap_ch, S == 1 ? d.n_chunks : want_c, 0, sizeof(trp_chunk)))) return fail_free(rc);
+            if (want_ch && (rc = grow((void**)&out->chunks, &cap_ch, S == 1 ? d.n_chunks : want_c, 0, sizeof(trp_chunk)))) return fail_free(rc);
+            if (want_ct) {
+                if ((rc = grow((void**)&ctext->text, &cap_ct, S == 1 ? n_ct : (u64)((double)n_ct * scale) + (1u << 20), 0, 1))) return fail_free(rc);
+                if ((rc = grow((void**)&ctext->offsets, &cap_cto, (S == 1 ? d.n_chunks : want_c) + 1, 0, sizeof(u64)))) return fail_free(rc);
+            }
         }
-        if (base_d + d.n_denoised > cap_den &&
+        if (want_den && base_d + d.n_denoised > cap_den &&
             (rc = grow((void**)&out->denoised, &cap_den, base_d + d.n_denoised, base_d, 1))) return fail_free(rc);
-        if (base_t + d.n_tokens > cap_tok) {
+        if (want_tok && base_t + d.n_tokens > cap_tok) {
             u64 tcap = cap_tok;
             if ((rc = grow((void**)&out->tok_start, &tcap, base_t + d.n_tokens, base_t, sizeof(u32)))) return fail_free(rc);
             if ((rc = grow((void**)&out->tok_len, &cap_tok, base_t + d.n_tokens, base_t, sizeof(u32)))) return fail_free(rc);
         }
-        if (base_c + d.n_chunks > cap_ch &&
+        if (want_ch && base_c + d.n_chunks > cap_ch &&
             (rc = grow((void**)&out->chunks, &cap_ch, base_c + d.n_chunks, base_c, sizeof(trp_chunk)))) return fail_free(rc);
+        if (want_ct) {
+            if (base_x + n_ct > cap_ct && (rc = grow((void**)&ctext->text, &cap_ct, base_x + n_ct, base_x, 1))) return fail_free(rc);
+            if (base_c + d.n_chunks + 1 > cap_cto &&
+                (rc = grow((void**)&ctext->offsets, &cap_cto, base_c + d.n_chunks + 1, base_c + 1, sizeof(u64)))) return fail_free(rc);
+        }
         // shift on the device, then copy to the final position
         hipStream_t st = x->stream;
         auto blocks = [](u64 n) { return dim3((unsigned)((n + 255) / 256)); };
+        if (want_ct && base_x) hipLaunchKernelGGL(k_add_u64, blocks(d.n_chunks + 1), dim3(256), 0, st, d_cto, d.n_chunks + 1, base_x);
         if (base_d && d.n_tokens) hipLaunchKernelGGL(k_add_u32, blocks(d.n_tokens), dim3(256), 0, st, d.tok_start, d.n_tokens, (u32)base_d);
         if (base_d) hipLaunchKernelGGL(k_add_u64, blocks(Rs + 1), dim3(256), 0, st, d.denoised_offsets, Rs + 1, base_d);
         if (base_t) hipLaunchKernelGGL(k_add_u64, blocks(Rs + 1), dim3(256), 0, st, d.tok_offsets, Rs + 1, base_t);
@@ -2761,10 +2780,12 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
             if (n) HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st));
             return TRP_OK;
         };
-        if ((rc = back(out->denoised + base_d, d.denoised, d.n_denoised))) return fail_free(rc);
-        if ((rc = back(out->tok_start + base_t, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
-        if ((rc = back(out->tok_len + base_t, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
-        if ((rc = back(out->chunks + base_c, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
+        if (want_den && (rc = back(out->denoised + base_d, d.denoised, d.n_denoised))) return fail_free(rc);
+        if (want_tok && (rc = back(out->tok_start + base_t, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+        if (want_tok && (rc = back(out->tok_len + base_t, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+        if (want_ch && (rc = back(out->chunks + base_c, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
+        if (want_ct && (rc = back(ctext->text + base_x, d_ct, n_ct))) return fail_free(rc);
+        if (want_ct && (rc = back(ctext->offsets + base_c, d_cto, (d.n_chunks + 1) * sizeof(u64)))) return fail_free(rc);
         if ((rc = back(out->denoised_offsets + r0, d.denoised_offsets, (Rs + 1) * sizeof(u64)))) return fail_free(rc);
         if ((rc = back(out->tok_offsets + r0, d.tok_offsets, (Rs + 1) * sizeof(u64)))) return fail_free(rc);
         if ((rc = back(out->chunk_offsets + r0, d.chunk_offsets, (Rs + 1) * sizeof(u64)))) return fail_free(rc);
@@ -2772,8 +2793,10 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
         base_d += d.n_denoised;
         base_t += d.n_tokens;
         base_c += d.n_chunks;
+        base_x += n_ct;
     }
     if ((rc = sync_all())) return fail_free(rc);
+    if (want_ct) ctext->n_bytes = base_x;
     out->n_records = R;
     out->n_denoised = base_d;
     out->n_tokens = base_t;
@@ -2782,8 +2805,10 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
 }
 
 static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
-                    trp_result* out) {
+                    trp_result* out, uint32_t outputs = TRP_OUT_ALL, trp_chunk_text* ctext = nullptr) {
     if (!c || !out || !offsets) return fail(TRP_E_ARG, "null argument");
+    if ((outputs & TRP_OUT_CHUNK_TEXT) && !ctext) return fail(TRP_E_ARG, "chunk text requested without a place for it");
+    if (ctext) memset(ctext, 0, sizeof(*ctext));
     if (offsets[0] != 0) return fail(TRP_E_ARG, "offsets[0] must be 0");
     const u64 N = offsets[R];
     if (N && !bytes) return fail(TRP_E_ARG, "bytes is null");
@@ -2793,7 +2818,7 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         if (offsets[r + 1] < offsets[r]) return fail(TRP_E_ARG, "offsets must be non-decreasing");
     const char* no_pipe = getenv("TRP_NO_PIPELINE");
     if (N >= PIPE_MIN_BYTES && R >= 2 && dc.denoise_enabled && !(no_pipe && atoi(no_pipe)))
-        return run_host_pipelined(c, bytes, offsets, R, dc, out);
+        return run_host_pipelined(c, bytes, offsets, R, dc, outputs, out, ctext);
     int rc;
     if ((rc = c->in_bytes.ensure(N + 64))) return rc;
     if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
@@ -2814,15 +2839,30 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         return TRP_OK;
     };
     // on failure: wait for the copies already enqueued, then hand the arrays taken so far back to the pool
-    auto fail_free = [&](int code) { (void)hipStreamSynchronize(c->stream); trp_result_free(out); return code; };
-    if ((rc = grab((void**)&out->denoised, d.denoised, d.n_denoised))) return fail_free(rc);
+    auto fail_free = [&](int code) {
+        (void)hipStreamSynchronize(c->stream);
+        trp_result_free(out);
+        if (ctext) { host_pool().release(ctext->text); host_pool().release(ctext->offsets); memset(ctext, 0, sizeof(*ctext)); }
+        return code;
+    };
+    if ((outputs & TRP_OUT_TEXT) && (rc = grab((void**)&out->denoised, d.denoised, d.n_denoised))) return fail_free(rc);
     if ((rc = grab((void**)&out->denoised_offsets, d.denoised_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
     if ((rc = grab((void**)&out->dropped, d.dropped, R))) return fail_free(rc);
-    if ((rc = grab((void**)&out->tok_start, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
-    if ((rc = grab((void**)&out->tok_len, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+    if ((outputs & TRP_OUT_TOKENS) && (rc = grab((void**)&out->tok_start, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
+    if ((outputs & TRP_OUT_TOKENS) && (rc = grab((void**)&out->tok_len, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
     if ((rc = grab((void**)&out->tok_offsets, d.tok_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
-    if ((rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
+    if ((outputs & TRP_OUT_CHUNKS) && (rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
     if ((rc = grab((void**)&out->chunk_offsets, d.chunk_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
+    if (outputs & TRP_OUT_CHUNK_TEXT) {
+        uint8_t* d_ct = nullptr;
+        uint64_t* d_cto = nullptr;
+        uint64_t n_ct = 0;
+        if ((rc = render_text(c, reinterpret_cast<const ChunkDesc*>(d.chunks), d.n_chunks, d.chunk_offsets, &d_ct, &d_cto, &n_ct)))
+            return fail_free(rc);
+        if ((rc = grab((void**)&ctext->text, d_ct, n_ct))) return fail_free(rc);
+        if ((rc = grab((void**)&ctext->offsets, d_cto, (d.n_chunks + 1) * sizeof(u64)))) return fail_free(rc);
+        ctext->n_bytes = n_ct;
+    }
     {
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return fail_free(fail(TRP_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)));
@@ -2836,6 +2876,22 @@ int trp_preprocess_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
     int rc = make_devcfg(cfg, &dc);
     if (rc) return rc;
     return run_host(c, bytes, offsets, R, dc, out);
+}
+
+int trp_preprocess_batch_select(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R,
+                                const trp_config* cfg, uint32_t outputs, trp_result* out, trp_chunk_text* chunk_text) {
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    if (outputs & ~(TRP_OUT_ALL | TRP_OUT_CHUNK_TEXT)) return fail(TRP_E_ARG, "unknown output selector");
+    return run_host(c, bytes, offsets, R, dc, out, outputs, chunk_text);
+}
+
+void trp_chunk_text_free(trp_chunk_text* t) {
+    if (!t) return;
+    host_pool().release(t->text);
+    host_pool().release(t->offsets);
+    memset(t, 0, sizeof(*t));
 }
 
 int trp_normalize_batch(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, trp_result* out) {

@@ -12,11 +12,16 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <exception>
 #include <map>
+#include <mutex>
 #include <optional>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <tuple>
 #include <vector>
 
 #include "../../include/triplets_amd.h"
@@ -171,6 +176,21 @@ public:
         }
         return run_packed(bytes.data(), offs.data(), sections.size(), st);
     }
+    // Only the arrays named by `outputs` (TRP_OUT_* flags) travel back; the per-record arrays always do.
+    BatchResult run_select(const std::vector<std::string_view>& sections, const ChunkingStrategy& st, uint32_t outputs) {
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> offs(1, 0);
+        for (auto s : sections) {
+            bytes.insert(bytes.end(), s.begin(), s.end());
+            offs.push_back(bytes.size());
+        }
+        auto ov = detail::overlaps_of(st);
+        trp_config c = detail::make_config(st, ov);
+        BatchResult out;
+        out.weight_ = st.summary_fallback_weight;
+        check(trp_preprocess_batch_select(ctx_.raw(), bytes.data(), offs.data(), sections.size(), &c, outputs, &out.r_, nullptr));
+        return out;
+    }
     BatchResult run_packed(const uint8_t* bytes, const uint64_t* offsets, size_t n, const ChunkingStrategy& st) {
         auto ov = detail::overlaps_of(st);
         trp_config c = detail::make_config(st, ov);
@@ -256,11 +276,17 @@ private:
     Context& ctx_;
 };
 
-// Chunk table filled by one GPU batch and served per (record id, section index): what a sampler needs to
-// call a GPU-backed chunker once per chunk selection (the reference calls ChunkingAlgorithm::materialize
-// per selection, src/sampler/mod.rs:2510-2537, and re-tokenises every section when it refreshes its
-// record cache, :1803-1836 - the place to call prefill).  token_count answers what
-// record_has_long_anchor_or_context_section (:1765-1773) asks without tokenising again.
+// Chunk table filled by GPU batches and served per (record id, section index): what a sampler needs to call
+// a GPU-backed chunker once per chunk selection.  The reference calls ChunkingAlgorithm::materialize per
+// selection, concurrently from its worker threads (`Send + Sync`, src/chunking/algorithm.rs:5,
+// src/sampler/mod.rs:2510-2537), and tokenises the RAW text of every section when it refreshes its record
+// cache (record_has_long_anchor_or_context_section, src/sampler/mod.rs:1803-1812) - the place to call prefill.
+//
+// Thread safety: every member may be called from any number of threads.  Lookups take a shared lock.  The GPU
+// context is used by one thread at a time; sections that miss the table while another thread is on the GPU
+// are queued and computed together, as one batch, by whichever thread gets the GPU next.
+// The table is keyed by the strategy as well (window / overlap / fallback sizes and the denoiser settings):
+// a changed ChunkingStrategy never sees chunks made for another one.
 class ChunkCache {
 public:
     struct SectionRef {
@@ -270,42 +296,168 @@ public:
     };
     explicit ChunkCache(Context& ctx) : ctx_(ctx) {}
 
+    // One batch for the chunks (with the strategy's denoiser, if any) and, when a denoiser is registered, one
+    // pass-through batch over the same sections for the raw token counts.
     void prefill(const ChunkingStrategy& st, const std::vector<SectionRef>& sections) {
+        std::lock_guard<std::mutex> gpu(gpu_mu_);
+        compute(st, sections);
+    }
+    // The chunks of one section (SlidingWindowChunker::materialize, sliding_window.rs:11-117).
+    std::vector<RecordChunk> materialize(const ChunkingStrategy& st, const std::string& record_id, size_t section_idx,
+                                         std::string_view section_text) {
+        const Key key{strategy_hash(st), record_id, section_idx};
+        {
+            std::shared_lock<std::shared_mutex> rd(table_mu_);
+            auto it = table_.find(key);
+            if (it != table_.end()) return it->second.chunks;
+        }
+        // miss: join the queue; the first thread to get the GPU computes everything queued for this strategy
+        Pending me{&st, SectionRef{record_id, section_idx, section_text}, key, false, nullptr};
+        {
+            std::lock_guard<std::mutex> q(queue_mu_);
+            queue_.push_back(&me);
+        }
+        {
+            std::lock_guard<std::mutex> gpu(gpu_mu_);
+            if (!me.done) drain();
+        }
+        if (me.error) std::rethrow_exception(me.error);
+        std::shared_lock<std::shared_mutex> rd(table_mu_);
+        return table_.at(key).chunks;
+    }
+    // WhitespaceTokenizer.token_count(&section.text) of the RAW section text - what the reference's sampler
+    // compares with max_window_tokens (src/sampler/mod.rs:1810) - for a section that was prefilled.
+    std::optional<size_t> token_count(const std::string& record_id, size_t section_idx) const {
+        std::shared_lock<std::shared_mutex> rd(table_mu_);
+        auto it = raw_tokens_.find({record_id, section_idx});
+        if (it == raw_tokens_.end()) return std::nullopt;
+        return it->second;
+    }
+    // Token count of the preprocessed text (what the windows of materialize are cut from).
+    std::optional<size_t> preprocessed_token_count(const ChunkingStrategy& st, const std::string& record_id,
+                                                   size_t section_idx) const {
+        std::shared_lock<std::shared_mutex> rd(table_mu_);
+        auto it = table_.find(Key{strategy_hash(st), record_id, section_idx});
+        if (it == table_.end()) return std::nullopt;
+        return it->second.tokens;
+    }
+    size_t size() const {
+        std::shared_lock<std::shared_mutex> rd(table_mu_);
+        return table_.size();
+    }
+    void clear() {
+        std::unique_lock<std::shared_mutex> wr(table_mu_);
+        table_.clear();
+        raw_tokens_.clear();
+    }
+    size_t gpu_batches() const { return batches_.load(); }   // batches run so far (for tests and tuning)
+
+    // FNV-1a over everything of the strategy that changes the result.
+    static uint64_t strategy_hash(const ChunkingStrategy& st) {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) {
+            for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xFFu; h *= 1099511628211ull; }
+        };
+        mix(st.max_window_tokens);
+        mix(st.overlap_tokens.size());
+        for (size_t o : st.overlap_tokens) mix(o);
+        mix(st.summary_fallback_tokens);
+        uint32_t w, r = 0;
+        std::memcpy(&w, &st.summary_fallback_weight, 4);
+        mix(w);
+        const bool on = st.denoiser && st.denoiser->enabled;
+        mix(on);
+        if (on) {
+            std::memcpy(&r, &st.denoiser->max_digit_ratio, 4);
+            mix(r);
+            mix(st.denoiser->strip_markdown);
+        }
+        return h;
+    }
+
+private:
+    struct Key {
+        uint64_t strategy;
+        std::string record_id;
+        size_t section_idx;
+        bool operator<(const Key& o) const {
+            return std::tie(strategy, record_id, section_idx) < std::tie(o.strategy, o.record_id, o.section_idx);
+        }
+    };
+    struct Entry {
+        std::vector<RecordChunk> chunks;
+        size_t tokens = 0;
+    };
+    struct Pending {
+        const ChunkingStrategy* st;
+        SectionRef ref;
+        Key key;
+        bool done;
+        std::exception_ptr error;
+    };
+
+    // gpu_mu_ held.  Everything queued right now, one batch per strategy.
+    void drain() {
+        std::vector<Pending*> work;
+        {
+            std::lock_guard<std::mutex> q(queue_mu_);
+            work.swap(queue_);
+        }
+        while (!work.empty()) {
+            const uint64_t h = work.front()->key.strategy;
+            std::vector<Pending*> same, rest;
+            for (Pending* p : work) (p->key.strategy == h ? same : rest).push_back(p);
+            std::vector<SectionRef> refs;
+            for (Pending* p : same) refs.push_back(p->ref);
+            std::exception_ptr err;
+            try {
+                compute(*same.front()->st, refs);
+            } catch (...) {
+                err = std::current_exception();
+            }
+            for (Pending* p : same) { p->error = err; p->done = true; }
+            work.swap(rest);
+        }
+    }
+    // gpu_mu_ held.
+    void compute(const ChunkingStrategy& st, const std::vector<SectionRef>& sections) {
+        if (sections.empty()) return;
         std::vector<std::string_view> texts;
         texts.reserve(sections.size());
         for (const auto& s : sections) texts.push_back(s.text);
         BatchPreprocessor bp(ctx_);
         BatchResult r = bp.run(texts, st);
+        batches_++;
+        std::vector<size_t> raw(sections.size());
+        if (st.denoiser && st.denoiser->enabled) {
+            ChunkingStrategy plain = st;
+            plain.denoiser.reset();
+            BatchResult t = bp.run_select(texts, plain, 0);   // per-record arrays only: the token offsets
+            batches_++;
+            for (size_t i = 0; i < sections.size(); i++) raw[i] = t.token_count(i);
+        } else {
+            for (size_t i = 0; i < sections.size(); i++) raw[i] = r.token_count(i);
+        }
+        const uint64_t h = strategy_hash(st);
+        std::vector<Entry> made(sections.size());
         for (size_t i = 0; i < sections.size(); i++) {
-            Entry e;
-            e.chunks = r.chunks(i, sections[i].record_id, sections[i].section_idx);
-            e.tokens = r.token_count(i);
-            table_[{sections[i].record_id, sections[i].section_idx}] = std::move(e);
+            made[i].chunks = r.chunks(i, sections[i].record_id, sections[i].section_idx);
+            made[i].tokens = r.token_count(i);
+        }
+        std::unique_lock<std::shared_mutex> wr(table_mu_);
+        for (size_t i = 0; i < sections.size(); i++) {
+            table_[Key{h, sections[i].record_id, sections[i].section_idx}] = std::move(made[i]);
+            raw_tokens_[{sections[i].record_id, sections[i].section_idx}] = raw[i];
         }
     }
-    // The chunks of one section; a section that was not prefilled is computed as a batch of one.
-    std::vector<RecordChunk> materialize(const ChunkingStrategy& st, const std::string& record_id, size_t section_idx,
-                                         std::string_view section_text) {
-        auto it = table_.find({record_id, section_idx});
-        if (it != table_.end()) return it->second.chunks;
-        prefill(st, {SectionRef{record_id, section_idx, section_text}});
-        return table_[{record_id, section_idx}].chunks;
-    }
-    std::optional<size_t> token_count(const std::string& record_id, size_t section_idx) const {
-        auto it = table_.find({record_id, section_idx});
-        if (it == table_.end()) return std::nullopt;
-        return it->second.tokens;
-    }
-    size_t size() const { return table_.size(); }
-    void clear() { table_.clear(); }
 
-private:
-    struct Entry {
-        std::vector<RecordChunk> chunks;
-        size_t tokens = 0;
-    };
     Context& ctx_;
-    std::map<std::pair<std::string, size_t>, Entry> table_;
+    mutable std::shared_mutex table_mu_;
+    std::mutex gpu_mu_, queue_mu_;
+    std::vector<Pending*> queue_;
+    std::map<Key, Entry> table_;
+    std::map<std::pair<std::string, size_t>, size_t> raw_tokens_;
+    std::atomic<size_t> batches_{0};
 };
 
 }  // namespace triplets_amd

@@ -50,6 +50,13 @@ class _Result(C.Structure):
                 ("n_chunks", C.c_uint64)]
 
 
+class _ChunkText(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("offsets", C.c_void_p), ("n_bytes", C.c_uint64)]
+
+
+OUT_TEXT, OUT_TOKENS, OUT_CHUNKS, OUT_CHUNK_TEXT, OUT_ALL = 1, 2, 4, 8, 7
+
+
 class _KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms", C.c_float)]
 
@@ -63,7 +70,8 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_materialize_chunk_text_device", "trp_denoise", "trp_tokenize", "trp_token_count",
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
            "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
-           "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event", "trp_chunk_bodies_device", "trp_bm25_texts_device"]
+           "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event", "trp_chunk_bodies_device", "trp_bm25_texts_device", "trp_preprocess_batch_select",
+           "trp_chunk_text_free"]
 
 _lib = None
 
@@ -94,6 +102,9 @@ def load_library():
     L.trp_preprocess_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.POINTER(_Config), C.POINTER(_Result)]
     L.trp_result_free.argtypes = [C.POINTER(_Result)]
+    L.trp_preprocess_batch_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Config),
+                                              C.c_uint32, C.POINTER(_Result), C.POINTER(_ChunkText)]
+    L.trp_chunk_text_free.argtypes = [C.POINTER(_ChunkText)]
     L.trp_preprocess_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                               C.c_uint64, C.POINTER(_Config), C.POINTER(_Result)]
     L.trp_submit_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
@@ -345,7 +356,7 @@ class Context:
     def _host_result(self, res, R) -> "BatchResult":
         def arr(ptr, n, dt):
             dt = np.dtype(dt)
-            if not n:
+            if not n or not ptr:
                 return np.zeros(0, dtype=dt)
             return np.frombuffer(C.string_at(ptr, int(n) * dt.itemsize), dtype=dt).copy()
 
@@ -374,6 +385,29 @@ class Context:
         _check(self._L.trp_preprocess_batch(self._h, data.ctypes.data if data.size else None,
                                             offsets.ctypes.data, R, C.byref(cfg), C.byref(res)))
         return self._host_result(res, R)
+
+    def preprocess_batch_select(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
+                                strategy: ChunkingStrategy, outputs: int) -> BatchResult:
+        """preprocess_batch returning only the arrays named by `outputs` (OUT_* flags); arrays that were not
+        selected are empty.  With OUT_CHUNK_TEXT the result has chunk_text (uint8) and chunk_text_offsets."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        R = len(offsets) - 1
+        cfg = _make_cfg(denoiser, strategy)
+        res, ct = _Result(), _ChunkText()
+        _check(self._L.trp_preprocess_batch_select(self._h, data.ctypes.data if data.size else None,
+                                                   offsets.ctypes.data, R, C.byref(cfg), int(outputs), C.byref(res),
+                                                   C.byref(ct) if outputs & OUT_CHUNK_TEXT else None))
+        n_chunks = int(res.n_chunks)
+        text = offs = None
+        if outputs & OUT_CHUNK_TEXT:
+            offs = np.frombuffer(C.string_at(ct.offsets, (n_chunks + 1) * 8), dtype=np.uint64).copy()
+            text = (np.frombuffer(C.string_at(ct.text, int(ct.n_bytes)), dtype=np.uint8).copy() if ct.n_bytes
+                    else np.zeros(0, np.uint8))
+            self._L.trp_chunk_text_free(C.byref(ct))
+        out = self._host_result(res, R)
+        out.chunk_text_bytes, out.chunk_text_offsets = text, offs
+        return out
 
     def normalize_batch(self, data: np.ndarray, offsets: np.ndarray) -> BatchResult:
         """normalize_inline_whitespace (src/utils.rs:18-33) of every record of a packed host batch."""

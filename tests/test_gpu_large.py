@@ -221,3 +221,36 @@ def test_host_path_pipelined_equals_single_shot():
         again = ctx.preprocess_batch(data, offs, den, st)      # buffers and pool blocks are reused
         assert_same(one, again, None, "pipelined host path, second call, config " + name)
         ctx.close()
+
+
+def test_host_path_output_selection():
+    """trp_preprocess_batch_select: the selected arrays equal those of the full call, the others stay away;
+    chunk text rendered on the GPU equals the text rebuilt from the full result.  Small batch (one shot) and a
+    batch large enough for the pipelined sub-batches."""
+    import corpusgen
+    den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy(256, [32, 64], 0.35, 128)
+    ctx = T.Context(0)
+    for nbytes in (3_000_000, 400_000_000):
+        data, offs = corpusgen.config_d(nbytes, 11, 16)
+        full = ctx.preprocess_batch(data, offs, den, st)
+        for mask in (0, T.OUT_CHUNKS | T.OUT_CHUNK_TEXT, T.OUT_TEXT, T.OUT_TOKENS | T.OUT_CHUNKS, T.OUT_ALL | T.OUT_CHUNK_TEXT):
+            got = ctx.preprocess_batch_select(data, offs, den, st, mask)
+            for k in ("denoised_offsets", "tok_offsets", "chunk_offsets", "dropped"):
+                assert np.array_equal(getattr(got, k), getattr(full, k)), (nbytes, mask, k)
+            assert (got.n_denoised, got.n_tokens, got.n_chunks) == (full.n_denoised, full.n_tokens, full.n_chunks)
+            for flag, names in ((T.OUT_TEXT, ("denoised",)), (T.OUT_TOKENS, ("tok_start", "tok_len")), (T.OUT_CHUNKS, ("chunks",))):
+                for k in names:
+                    if mask & flag:
+                        assert np.array_equal(getattr(got, k), getattr(full, k)), (nbytes, mask, k)
+                    else:
+                        assert len(getattr(got, k)) == 0, (nbytes, mask, k)
+            if mask & T.OUT_CHUNK_TEXT:
+                o = got.chunk_text_offsets
+                assert len(o) == full.n_chunks + 1 and o[0] == 0 and int(o[-1]) == len(got.chunk_text_bytes)
+                rng = np.random.default_rng(3)
+                picks = set(rng.integers(0, full.n_chunks, 3000).tolist()) | {0, full.n_chunks - 1}
+                big = int(np.argmax(np.diff(full.chunk_offsets.astype(np.int64))))
+                picks |= set(range(int(full.chunk_offsets[big]), int(full.chunk_offsets[big]) + 5))
+                for c in picks:
+                    assert got.chunk_text_bytes[int(o[c]):int(o[c + 1])].tobytes() == full.chunk_text(c), (nbytes, c)
+    ctx.close()
