@@ -3,6 +3,8 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const TRP_OK: c_int = 0;
+pub const TRP_MAX_BATCH_BYTES: u64 = 0xFFFF_0000;
+pub const TRP_OUT_ALL: u32 = 7;
 
 #[repr(C)]
 pub struct trp_ctx {
@@ -60,6 +62,17 @@ extern "C" {
         n_records: u64,
         cfg: *const trp_config,
         out: *mut trp_result,
+    ) -> c_int;
+    /// Same call, returning only the arrays named by `outputs` (per-record arrays always come back).
+    pub fn trp_preprocess_batch_select(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        cfg: *const trp_config,
+        outputs: u32,
+        out: *mut trp_result,
+        chunk_text: *mut c_void,
     ) -> c_int;
     pub fn trp_result_free(r: *mut trp_result);
     pub fn trp_denoise(

@@ -2,15 +2,17 @@
 //!
 //! * [`GpuSlidingWindowChunker`] implements `triplets::ChunkingAlgorithm` (the trait the sampler is
 //!   given through `TripletSampler::new_with_chunker`).  The sampler asks for the chunks of ONE section
-//!   at a time, many times per batch, so the chunker answers from a table that [`GpuSlidingWindowChunker::
-//!   prefill`] computes for a whole set of records in one GPU batch; a section that is not in the table
-//!   is computed as a batch of one.
+//!   at a time, many times per batch and from several worker threads, so the chunker answers from a
+//!   table that [`GpuSlidingWindowChunker::prefill`] computes for a whole set of records in one GPU
+//!   batch; sections that miss the table are queued and computed together by whichever thread gets
+//!   the GPU next.
 //! * [`GpuDenoiserPreprocessor`] implements `triplets::TextPreprocessor` for callers that only want
 //!   the denoiser.
 //!
-//! The library never falls back to a CPU implementation: when the GPU call fails the chunker returns no
-//! chunks (the sampler then tries another section, exactly as for a section the denoiser dropped) and
-//! the error text is reported through `log_error`.
+//! The library never falls back to a CPU implementation.  The traits have no error channel, so a GPU
+//! failure is kept as a sticky error ([`GpuSlidingWindowChunker::take_error`]) and reported through
+//! `log_error`; `prefill` returns it as a `Result`.  NOTE: this crate has not been compiled (the build
+//! environment has no Rust toolchain); the tested host sides are the C++ and Python ones.
 pub mod ffi;
 
 use std::collections::HashMap;
@@ -74,7 +76,14 @@ impl Drop for Batch {
 }
 
 impl Batch {
-    fn run(ctx: &Context, texts: &[&str], denoiser: Option<&DenoiserConfig>, st: &ChunkingStrategy) -> Option<Batch> {
+    /// `outputs`: TRP_OUT_* selection (0 = per-record arrays only, enough for token counts).
+    fn run(
+        ctx: &Context,
+        texts: &[&str],
+        denoiser: Option<&DenoiserConfig>,
+        st: &ChunkingStrategy,
+        outputs: u32,
+    ) -> Result<Batch, String> {
         let mut bytes = Vec::with_capacity(texts.iter().map(|t| t.len()).sum());
         let mut offsets = Vec::with_capacity(texts.len() + 1);
         offsets.push(0u64);
@@ -95,14 +104,29 @@ impl Batch {
         let mut raw: ffi::trp_result = unsafe { std::mem::zeroed() };
         let guard = ctx.raw.lock().unwrap();
         let rc = unsafe {
-            ffi::trp_preprocess_batch(*guard, bytes.as_ptr(), offsets.as_ptr(), texts.len() as u64, &cfg, &mut raw)
+            ffi::trp_preprocess_batch_select(
+                *guard,
+                bytes.as_ptr(),
+                offsets.as_ptr(),
+                texts.len() as u64,
+                &cfg,
+                outputs,
+                &mut raw,
+                std::ptr::null_mut(),
+            )
         };
         drop(guard);
         if rc != ffi::TRP_OK {
-            log_error("trp_preprocess_batch");
-            return None;
+            let e = last_error();
+            log_error("trp_preprocess_batch_select");
+            return Err(e);
         }
-        Some(Batch { raw })
+        Ok(Batch { raw })
+    }
+
+    fn token_count(&self, r: usize) -> usize {
+        let off = Self::slice(self.raw.tok_offsets, self.raw.n_records as usize + 1);
+        (off[r + 1] - off[r]) as usize
     }
 
     fn slice<T>(p: *const T, n: usize) -> &'static [T] {
@@ -152,42 +176,169 @@ impl Batch {
     }
 }
 
-type Key = (String, usize);
+type Proto = (ChunkView, String, usize);
+/// (strategy fingerprint, record id, section index): chunks made for one `ChunkingStrategy` are never
+/// served for another.
+type Key = (u64, String, usize);
+
+/// FNV-1a over everything of the strategy and the denoiser settings that changes the result.
+fn strategy_fingerprint(st: &ChunkingStrategy, den: Option<&DenoiserConfig>) -> u64 {
+    let mut h: u64 = 0xcbf2_9ce4_8422_2325;
+    let mut mix = |v: u64| {
+        for b in v.to_le_bytes() {
+            h ^= b as u64;
+            h = h.wrapping_mul(0x0000_0100_0000_01b3);
+        }
+    };
+    mix(st.max_window_tokens as u64);
+    mix(st.overlap_tokens.len() as u64);
+    for &o in &st.overlap_tokens {
+        mix(o as u64);
+    }
+    mix(st.summary_fallback_tokens as u64);
+    mix(st.summary_fallback_weight.to_bits() as u64);
+    let on = den.map_or(false, |d| d.enabled);
+    mix(on as u64);
+    if let Some(d) = den.filter(|d| d.enabled) {
+        mix(d.max_digit_ratio.to_bits() as u64);
+        mix(d.strip_markdown as u64);
+    }
+    h
+}
+
+struct Miss {
+    key: Key,
+    text: *const str, // the caller's section text; the caller is blocked until `done`
+    strategy: *const ChunkingStrategy,
+    done: bool,
+}
 
 /// `ChunkingAlgorithm` served from GPU batches.  Build it with the denoiser settings it should apply
 /// (do NOT also register a `DenoiserPreprocessor` on the strategy: the GPU path already denoises).
+///
+/// A strategy that carries registered preprocessors (`strategy.preprocessors()` non-empty) cannot be
+/// served: the GPU path implements the denoiser only, and running arbitrary host preprocessors would
+/// need the reference's CPU chunker.  Such a call records an error, logs it and returns no chunks;
+/// give such samplers the reference's own `SlidingWindowChunker`.
 pub struct GpuSlidingWindowChunker {
     ctx: Context,
     denoiser: Option<DenoiserConfig>,
-    table: RwLock<HashMap<Key, Vec<(ChunkView, String, usize)>>>,
+    table: RwLock<HashMap<Key, Vec<Proto>>>,
+    raw_tokens: RwLock<HashMap<(String, usize), usize>>,
+    queue: Mutex<Vec<*mut Miss>>,
+    gpu: Mutex<()>,
+    error: Mutex<Option<String>>,
 }
+unsafe impl Send for GpuSlidingWindowChunker {}
+unsafe impl Sync for GpuSlidingWindowChunker {}
 
 impl GpuSlidingWindowChunker {
     pub fn new(device: i32, denoiser: Option<DenoiserConfig>) -> Result<Self, String> {
-        Ok(Self { ctx: Context::new(device)?, denoiser, table: RwLock::new(HashMap::new()) })
+        Ok(Self {
+            ctx: Context::new(device)?,
+            denoiser,
+            table: RwLock::new(HashMap::new()),
+            raw_tokens: RwLock::new(HashMap::new()),
+            queue: Mutex::new(Vec::new()),
+            gpu: Mutex::new(()),
+            error: Mutex::new(None),
+        })
     }
 
-    /// Runs every section of `records` through the GPU in one batch and remembers the chunks.
-    /// Natural call site: where the sampler refreshes its record cache at ingest time.
-    pub fn prefill(&self, strategy: &ChunkingStrategy, records: &[DataRecord]) {
-        let mut keys = Vec::new();
-        let mut texts = Vec::new();
+    /// The first GPU failure since the last call, if any (the traits cannot return it).
+    pub fn take_error(&self) -> Option<String> {
+        self.error.lock().unwrap().take()
+    }
+
+    fn fail(&self, e: String) -> String {
+        let mut slot = self.error.lock().unwrap();
+        if slot.is_none() {
+            *slot = Some(e.clone());
+        }
+        e
+    }
+
+    /// Runs every section of `records` through the GPU and remembers the chunks and the token count of
+    /// the RAW section text (`WhitespaceTokenizer.token_count(&section.text)`, what
+    /// `record_has_long_anchor_or_context_section` asks, src/sampler/mod.rs:1803-1812).  Inputs larger
+    /// than one batch are split by record range.  Natural call site: where the sampler refreshes its
+    /// record cache at ingest time.
+    pub fn prefill(&self, strategy: &ChunkingStrategy, records: &[DataRecord]) -> Result<(), String> {
+        if !strategy.preprocessors().is_empty() {
+            return Err(self.fail("strategy has registered preprocessors: not served by the GPU chunker".into()));
+        }
+        let mut keys: Vec<(String, usize)> = Vec::new();
+        let mut texts: Vec<&str> = Vec::new();
         for rec in records {
             for (i, s) in rec.sections.iter().enumerate() {
                 keys.push((rec.id.to_string(), i));
                 texts.push(s.text.as_str());
             }
         }
-        if let Some(batch) = Batch::run(&self.ctx, &texts, self.denoiser.as_ref(), strategy) {
-            let mut table = self.table.write().unwrap();
-            for (r, key) in keys.into_iter().enumerate() {
-                table.insert(key, batch.chunks_of(r, strategy.summary_fallback_weight));
+        let _gpu = self.gpu.lock().unwrap();
+        let mut at = 0;
+        while at < texts.len() {
+            // as many sections as fit one batch (a single section above the limit fails in the library)
+            let (mut end, mut bytes) = (at, 0u64);
+            while end < texts.len() && (end == at || bytes + texts[end].len() as u64 <= ffi::TRP_MAX_BATCH_BYTES) {
+                bytes += texts[end].len() as u64;
+                end += 1;
             }
+            self.compute(strategy, &keys[at..end], &texts[at..end]).map_err(|e| self.fail(e))?;
+            at = end;
         }
+        Ok(())
+    }
+
+    /// `gpu` held.  One batch for the chunks and, with a denoiser, one pass-through batch for the raw counts.
+    fn compute(&self, strategy: &ChunkingStrategy, keys: &[(String, usize)], texts: &[&str]) -> Result<(), String> {
+        let batch = Batch::run(&self.ctx, texts, self.denoiser.as_ref(), strategy, ffi::TRP_OUT_ALL)?;
+        let denoising = self.denoiser.as_ref().map_or(false, |d| d.enabled);
+        let raw: Vec<usize> = if denoising {
+            let plain = Batch::run(&self.ctx, texts, None, strategy, 0)?;
+            (0..texts.len()).map(|r| plain.token_count(r)).collect()
+        } else {
+            (0..texts.len()).map(|r| batch.token_count(r)).collect()
+        };
+        let fp = strategy_fingerprint(strategy, self.denoiser.as_ref());
+        let protos: Vec<Vec<Proto>> =
+            (0..texts.len()).map(|r| batch.chunks_of(r, strategy.summary_fallback_weight)).collect();
+        let mut table = self.table.write().unwrap();
+        let mut counts = self.raw_tokens.write().unwrap();
+        for ((key, p), n) in keys.iter().zip(protos).zip(raw) {
+            table.insert((fp, key.0.clone(), key.1), p);
+            counts.insert(key.clone(), n);
+        }
+        Ok(())
+    }
+
+    /// Token count of the raw text of a prefilled section.
+    pub fn token_count(&self, record_id: &str, section_idx: usize) -> Option<usize> {
+        self.raw_tokens.read().unwrap().get(&(record_id.to_string(), section_idx)).copied()
     }
 
     pub fn clear(&self) {
         self.table.write().unwrap().clear();
+        self.raw_tokens.write().unwrap().clear();
+    }
+
+    /// `gpu` held: everything queued right now, one batch per strategy fingerprint.
+    fn drain(&self) {
+        let mut work: Vec<*mut Miss> = std::mem::take(&mut *self.queue.lock().unwrap());
+        while let Some(&first) = work.first() {
+            let fp = unsafe { (*first).key.0 };
+            let (same, rest): (Vec<_>, Vec<_>) = work.into_iter().partition(|&m| unsafe { (*m).key.0 == fp });
+            let keys: Vec<(String, usize)> = same.iter().map(|&m| unsafe { ((*m).key.1.clone(), (*m).key.2) }).collect();
+            let texts: Vec<&str> = same.iter().map(|&m| unsafe { &*(*m).text }).collect();
+            let strategy = unsafe { &*(*same[0]).strategy };
+            if let Err(e) = self.compute(strategy, &keys, &texts) {
+                self.fail(e);
+            }
+            for &m in &same {
+                unsafe { (*m).done = true };
+            }
+            work = rest;
+        }
     }
 }
 
@@ -199,15 +350,28 @@ impl ChunkingAlgorithm for GpuSlidingWindowChunker {
         section_idx: usize,
         section: &RecordSection,
     ) -> Vec<RecordChunk> {
-        let key = (record.id.to_string(), section_idx);
-        let protos = match self.table.read().unwrap().get(&key) {
-            Some(p) => p.clone(),
-            None => match Batch::run(&self.ctx, &[section.text.as_str()], self.denoiser.as_ref(), strategy) {
-                Some(b) => b.chunks_of(0, strategy.summary_fallback_weight),
-                None => return Vec::new(),
-            },
-        };
+        if !strategy.preprocessors().is_empty() {
+            self.fail("strategy has registered preprocessors: not served by the GPU chunker".into());
+            eprintln!("triplets-amd: strategy with registered preprocessors given to the GPU chunker; no chunks");
+            return Vec::new();
+        }
+        let key: Key = (strategy_fingerprint(strategy, self.denoiser.as_ref()), record.id.to_string(), section_idx);
+        let mut protos = self.table.read().unwrap().get(&key).cloned();
+        if protos.is_none() {
+            // miss: queue it; the first thread to get the GPU computes everything queued
+            let mut me = Miss { key: key.clone(), text: section.text.as_str(), strategy, done: false };
+            self.queue.lock().unwrap().push(&mut me);
+            {
+                let _gpu = self.gpu.lock().unwrap();
+                if !me.done {
+                    self.drain();
+                }
+            }
+            protos = self.table.read().unwrap().get(&key).cloned();
+        }
+        // a GPU failure leaves the section out of the table: the error is kept (take_error) and logged
         protos
+            .unwrap_or_default()
             .into_iter()
             .map(|(view, text, tokens_estimate)| RecordChunk {
                 record_id: record.id.clone(),
