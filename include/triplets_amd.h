@@ -172,6 +172,43 @@ int trp_submit_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t
                             uint64_t n_records, uint64_t n_bytes, const trp_config* cfg);
 int trp_wait_batch(trp_ctx* ctx, trp_result* out);
 
+/* trp_preprocess_batch_device for callers that cannot allocate GPU memory at the time of the call (code under
+ * HIP graph capture or in a tight serving loop, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  The call allocates and frees nothing, on the device or the host: every working array lives in a
+ * fixed scratch array that is part of the library's code object (about 25 MiB on each GPU the library is loaded
+ * on, held until the process ends), and every result array is the caller's device memory, described by
+ * trp_out_buffers:
+ *   denoised (16-byte aligned, denoised_cap >= n_bytes bytes; unused with the denoiser disabled, where the text
+ *   is the input itself), denoised_offsets / tok_offsets / chunk_offsets (n_records + 1 entries each), dropped
+ *   (n_records), tok_start / tok_len (tok_cap >= trp_token_bound(n_bytes, n_records) entries each), chunks
+ *   (chunk_cap entries).
+ * Limits: n_bytes <= TRP_NOALLOC_MAX_BYTES and n_records <= TRP_NOALLOC_MAX_RECORDS (TRP_E_TOO_LARGE beyond;
+ * split by record range); TRP_E_TOO_LARGE also when the batch has more chunks than chunk_cap (out->n_chunks
+ * then says how many) or more digit-heavy lines left to the work list than one per 64 bytes of text.  Results
+ * are identical to trp_preprocess_batch_device; `out` points into the caller's buffers.  The call returns after
+ * the kernels have completed, like trp_preprocess_batch_device.  All calls on one GPU share that GPU's scratch
+ * array, from whatever context or thread: calls that overlap in time on one GPU race and must be serialised by
+ * the caller.  The other entry points do not use the array. */
+#define TRP_NOALLOC_MAX_BYTES (32ull << 20)
+#define TRP_NOALLOC_MAX_RECORDS (1ull << 19)
+typedef struct {
+    uint8_t* denoised;
+    uint64_t denoised_cap;
+    uint64_t* denoised_offsets;
+    uint8_t* dropped;
+    uint32_t* tok_start;
+    uint32_t* tok_len;
+    uint64_t tok_cap;
+    uint64_t* tok_offsets;
+    trp_chunk* chunks;
+    uint64_t chunk_cap;
+    uint64_t* chunk_offsets;
+} trp_out_buffers;
+uint64_t trp_token_bound(uint64_t n_bytes, uint64_t n_records);
+int trp_preprocess_batch_device_noalloc(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                                        uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
+                                        const trp_out_buffers* buffers, trp_result* out);
+
 /* Copy `bytes` bytes of a device array of the last result into host memory (ordered on the context's
  * stream, returns when the copy is complete). */
 int trp_copy_to_host(trp_ctx* ctx, void* dst, const void* d_src, size_t bytes);

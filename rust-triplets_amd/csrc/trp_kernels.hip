@@ -1976,6 +1976,66 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// ---- fixed scratch memory of the entry point that allocates nothing (trp_preprocess_batch_device_noalloc) ----
+// Every GPU the library runs on holds one copy of this array from the moment the code object is loaded until
+// the process ends.  Host code never uses the array's name as an address (on the host it is only a handle for
+// hipGetSymbolAddress): scratch_of_device() asks the runtime once per device, with that device current, where
+// the device's copy lives, and everything else (kernel arguments, memsets) goes through that pointer.
+constexpr u64 NOALLOC_MAX_BYTES = TRP_NOALLOC_MAX_BYTES, NOALLOC_MAX_RECORDS = TRP_NOALLOC_MAX_RECORDS;
+constexpr u64 NOALLOC_G3_CAP = NOALLOC_MAX_BYTES / 64;   // one listed digit-heavy line per 64 bytes of text
+
+struct ScratchLayout {
+    size_t totals, rec_lo, SA, seedJ, seedS, far_list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial,
+        counts, g3list, plan, end;
+};
+constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr ScratchLayout scratch_layout() {
+    constexpr size_t nT = (NOALLOC_MAX_BYTES + TILE - 1) / TILE, nB = (NOALLOC_MAX_BYTES + BLOCK - 1) / BLOCK;
+    constexpr size_t R = NOALLOC_MAX_RECORDS;
+    constexpr size_t nPart = ((nT > R ? nT : R) + NT * 8 - 1) / (NT * 8) + 1;
+    ScratchLayout L = {};
+    size_t at = 0;
+    L.totals = at;     at = align256(at + 16 * sizeof(u64));
+    L.rec_lo = at;     at = align256(at + (nT + 2) * sizeof(u32));
+    L.SA = at;         at = align256(at + (nT + 1) * sizeof(J));
+    L.seedJ = at;      at = align256(at + (nT + 1) * sizeof(J));
+    L.seedS = at;      at = align256(at + (nT + 1) * sizeof(S));
+    L.far_list = at;   at = align256(at + (nT + 1) * sizeof(u32));
+    L.tile_bytes = at; at = align256(at + (nT + 1) * sizeof(u32));
+    L.tile_toks = at;  at = align256(at + (nT + 1) * sizeof(u32));
+    L.tile_flags = at; at = align256(at + (nT + 1) * sizeof(u32));
+    L.packed = at;     at = align256(at + (nT + 1) * sizeof(u64));
+    L.tile_base = at;  at = align256(at + (nT + 2) * sizeof(u64));
+    L.partial = at;    at = align256(at + nPart * sizeof(u64));
+    L.counts = at;     at = align256(at + (R + 1) * sizeof(u64));
+    L.g3list = at;     at = align256(at + NOALLOC_G3_CAP * sizeof(u64));
+    L.plan = at;       at = align256(at + (nB + 1) * sizeof(Plan));
+    L.end = at;
+    return L;
+}
+constexpr size_t SCRATCH_BYTES = scratch_layout().end;   // about 24.6 MiB
+static_assert(SCRATCH_BYTES <= ((size_t)32 << 20), "the fixed scratch array is meant to stay modest");
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static unsigned char* g_scratch_ptr[SCRATCH_MAX_DEVICES];   // device address of `scratch` on each GPU, once known
+
+// Device address of this GPU's copy of `scratch`.  `device` must be the current device.
+static int scratch_of_device(int device, unsigned char** out) {
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return fail(TRP_E_ARG, "device ordinal out of range");
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        unsigned char* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(TRP_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return TRP_OK;
+}
+
 struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1988,6 +2048,7 @@ struct trp_ctx {
     DevBuf heads;                       // head-of-record / chunk-body descriptors (trp_head_tokens_text_device, trp_chunk_bodies_device)
     DevBuf sel;                         // caller's selection arrays (chunk indices + budgets, document offsets)
     u64* h_totals = nullptr;            // pinned
+    unsigned char* scratch_ptr = nullptr;   // this GPU's copy of the fixed scratch array (see scratch_of_device)
     bool profiling = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
     std::vector<trp_kernel_time> last_profile;
@@ -2066,17 +2127,23 @@ int make_devcfg(const trp_config* cfg, DevCfg* d) {
     return TRP_OK;
 }
 
-int scan_u64(trp_ctx* c, const u64* in, u64 n, u64* out) {
-    u64 nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    if (nb == 0) nb = 1;
-    int rc = c->partial.ensure(nb * sizeof(u64));
-    if (rc) return rc;
-    u64* partial = c->partial.as<u64>();
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(NT), 0, c->stream, in, n, partial);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, c->stream, partial, nb);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(NT), 0, c->stream, in, n, partial, out);
+// Number of u64 partial sums scan_u64 needs for n inputs.
+u64 scan_partials(u64 n) {
+    const u64 nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    return nb ? nb : 1;
+}
+int scan_u64_with(hipStream_t st, u64* partial, const u64* in, u64 n, u64* out) {
+    const u64 nb = scan_partials(n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(NT), 0, st, in, n, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, st, partial, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(NT), 0, st, in, n, partial, out);
     HIPCHK(hipGetLastError());
     return TRP_OK;
+}
+int scan_u64(trp_ctx* c, const u64* in, u64 n, u64* out) {
+    int rc = c->partial.ensure(scan_partials(n) * sizeof(u64));
+    if (rc) return rc;
+    return scan_u64_with(c->stream, c->partial.as<u64>(), in, n, out);
 }
 
 // Upper bound of the number of chunks of a batch with N bytes and R records.
@@ -2108,7 +2175,13 @@ static int create_ctx(int device, hipStream_t stream, bool own, trp_ctx** out) {
         return fail(TRP_E_HIP, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(TRP_E_ARG, "device ordinal out of range");
     HIPCHK(hipSetDevice(device));
+    unsigned char* sp = nullptr;
+    {
+        int rc = scratch_of_device(device, &sp);
+        if (rc) return rc;
+    }
     trp_ctx* c = new trp_ctx();
+    c->scratch_ptr = sp;
     { const char* e2 = getenv("TRIPLETS_AMD_FORCE_SUMMARY"); c->force_summary = (e2 && atoi(e2)) ? 1u : 0u; }
     c->device = device;
     c->owns_stream = own;
@@ -2188,23 +2261,138 @@ __global__ void k_add_chunk_record(ChunkDesc* __restrict__ c, u64 n, u32 add) {
 }
 }  // namespace
 
+// Device memory one pass of the path works in: scratch arrays (sized by the batch) and the result arrays.
+struct PathBufs {
+    // scratch
+    u32* rec_lo;                  // nT + 2
+    J *SA, *seedJ;                // nT + 1 each
+    S* seedS;                     // nT + 1
+    u32* far_list;                // nT + 1
+    Plan* plan;                   // nB + 1
+    u64* g3list; u64 g3_cap;      // work list of digit-heavy lines
+    u32 *tile_bytes, *tile_toks, *tile_flags;   // nT + 1 each
+    u64 *packed, *tile_base;      // nT + 1, nT + 2
+    u64* partial;                 // scan_partials(max(nT, R))
+    u64* counts;                  // R + 1
+    u64* totals;                  // 16
+    // results
+    u8* denoised;
+    u64 *den_off, *tok_off, *chunk_off;
+    u8* dropped;
+    u32 *tok_start, *tok_len;
+    ChunkDesc* chunks; u64 chunk_cap;
+};
+
+// Token table entries a batch can need.  A token needs one byte, and two tokens of one record a separator byte
+// between them: a record of n bytes holds at most (n + 1) / 2 tokens, the batch at most
+// (N + non-empty records) / 2; a few entries of slack for the four-wide stores.
+static u64 token_bound(u64 N, u64 R) { return (N + std::min<u64>(R, N)) / 2 + 4; }
+
+// Enqueues the kernels of the whole path for one batch on `st`; nothing is allocated here.  `c` supplies the
+// profiling switches only.
+static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                        uint64_t R, uint64_t N, const DevCfg& dc) {
+    int rc;
+    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE;
+    const bool pass = !dc.denoise_enabled;
+    u32* rec_lo = B.rec_lo;
+    u32 *tbytes = B.tile_bytes, *ttoks = B.tile_toks, *tflags = B.tile_flags;
+    u64* tile_base = B.tile_base;
+    u64 *den_off = B.den_off, *tok_off = B.tok_off, *chunk_off = B.chunk_off;
+    u64* totals = B.totals;
+    Plan* plan = B.plan;
+    J* SA = B.SA;
+    HIPCHK(hipMemsetAsync(totals, 0, 16 * sizeof(u64), st));
+
+    {
+        Prof pr(c, "k_rec_lo");
+        hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + 2 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, rec_lo);
+    }
+    if (nT) {
+        if (!pass) {
+            u32* open_count = reinterpret_cast<u32*>(totals + 8);   // zeroed with the totals
+            { Prof pr(c, "k_seed");
+              const dim3 grid((unsigned)((nT + SEED_TPW * (NT / 64) - 1) / (SEED_TPW * (NT / 64))));
+              if (dc.normalize)
+                  hipLaunchKernelGGL(k_seed<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
+                                     B.seedJ, B.seedS, open_count);
+              else
+                  hipLaunchKernelGGL(k_seed<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
+                                     B.seedJ, B.seedS, open_count); }
+            // the next three return at once unless k_seed left tiles open
+            { Prof pr(c, "k_summary");
+              const dim3 grid((unsigned)std::min<u64>(nT, SUMMARY_GRID));
+              if (dc.normalize) hipLaunchKernelGGL(k_summary<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA);
+              else hipLaunchKernelGGL(k_summary<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA); }
+            { Prof pr(c, "k_tile_carry");
+              u32* far_count = reinterpret_cast<u32*>(totals + 7);   // zeroed with the totals
+              hipLaunchKernelGGL(k_tile_carry_near, dim3((unsigned)std::min<u64>((nT + 255) / 256, 1024)), dim3(256), 0, st, SA, nT,
+                                 open_count, B.seedJ, B.seedS, B.far_list, far_count);
+              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 1024)), dim3(NT), 0, st,
+                                 SA, nT, B.seedJ, B.seedS, B.far_list, far_count); }
+            { Prof pr(c, "k_plan");
+              if (dc.normalize)
+                  hipLaunchKernelGGL(k_plan<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
+                                     B.seedJ, B.seedS, dc, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
+                                     ttoks, tflags, c->plan_stop());
+              else
+                  hipLaunchKernelGGL(k_plan<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
+                                     B.seedJ, B.seedS, dc, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
+                                     ttoks, tflags, c->plan_stop()); }
+            { Prof pr(c, "k_gate3");
+              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
+                                 B.g3list, totals + 6, B.g3_cap, tbytes, ttoks, totals); }
+        } else {
+            Prof pr(c, "k_count_tokens");
+            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, tbytes, ttoks,
+                               tflags);
+        }
+        { Prof pr(c, "scan_tiles");
+          hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, tbytes, ttoks, tflags, nT,
+                             B.packed);
+          if ((rc = scan_u64_with(st, B.partial, B.packed, nT, tile_base))) return rc; }
+        { Prof pr(c, "k_emit");
+          if (pass)
+              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
+                                 d_offsets, rec_lo, R, N, nB, nT, (const Plan*)nullptr, tile_base, (u8*)nullptr, B.tok_start, B.tok_len,
+                                 den_off, tok_off, c->emit_stop());
+          else
+              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
+                                 d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, B.denoised, B.tok_start, B.tok_len,
+                                 den_off, tok_off, c->emit_stop()); }
+    }
+    { Prof pr(c, "k_finish_count");
+      hipLaunchKernelGGL(k_finish_count, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nT, rec_lo, R, N,
+                         pass ? 1 : 0, dc, den_off, tok_off, totals, B.counts, B.dropped); }
+    { Prof pr(c, "scan_chunks");
+      if ((rc = scan_u64_with(st, B.partial, B.counts, R, chunk_off))) return rc; }
+    { Prof pr(c, "k_chunk_emit");
+      hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, B.chunk_cap,
+                         B.chunks, totals); }
+    HIPCHK(hipGetLastError());
+    return TRP_OK;
+}
+
+static int check_batch_args(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N) {
+    if (!d_offsets) return fail(TRP_E_ARG, "offsets is null");
+    if (N && !d_bytes) return fail(TRP_E_ARG, "bytes is null");
+    if (((uintptr_t)d_bytes & 15u) != 0) return fail(TRP_E_ARG, "bytes must be 16-byte aligned");
+    if (N > TRP_MAX_BATCH_BYTES || R >= 0xFFFFFFFEull) return fail(TRP_E_TOO_LARGE, "batch too large: split it by record range");
+    return TRP_OK;
+}
+
 // Enqueues the whole path for one batch on the context's stream and returns without waiting.
 static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
                          const DevCfg& dc) {
     if (!c) return fail(TRP_E_ARG, "ctx is null");
     if (c->pending.active) return fail(TRP_E_ARG, "a batch is already in flight on this context");
-    if (!d_offsets) return fail(TRP_E_ARG, "offsets is null");
-    if (N && !d_bytes) return fail(TRP_E_ARG, "bytes is null");
-    if (((uintptr_t)d_bytes & 15u) != 0) return fail(TRP_E_ARG, "bytes must be 16-byte aligned");
-    if (N > TRP_MAX_BATCH_BYTES || R >= 0xFFFFFFFEull) return fail(TRP_E_TOO_LARGE, "batch too large: split it by record range");
     int rc;
+    if ((rc = check_batch_args(d_bytes, d_offsets, R, N))) return rc;
     HIPCHK(hipSetDevice(c->device));
     c->have_last = false;
     const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE;
     const bool pass = !dc.denoise_enabled;
-    // A token needs one byte, and two tokens of one record a separator byte between them: a record of n
-    // bytes holds at most (n + 1) / 2 tokens, the batch at most (N + non-empty records) / 2.
-    const u64 tok_cap = (N + std::min<u64>(R, N)) / 2 + 4;
+    const u64 tok_cap = token_bound(N, R);
     u64 chunk_cap = chunk_bound(N, R, dc);
     const u64 chunk_cap_limit = (u64)1 << 28;   // do not pre-allocate more than 8 GiB of descriptors
     if (chunk_cap > chunk_cap_limit) chunk_cap = chunk_cap_limit;
@@ -2220,6 +2408,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if ((rc = c->tile_flags.ensure((nT + 1) * sizeof(u32)))) return rc;
     if ((rc = c->packed.ensure((nT + 1) * sizeof(u64)))) return rc;
     if ((rc = c->tile_base.ensure((nT + 2) * sizeof(u64)))) return rc;
+    if ((rc = c->partial.ensure(scan_partials(std::max(nT, R)) * sizeof(u64)))) return rc;
     if ((rc = c->den_off.ensure((R + 1) * sizeof(u64)))) return rc;
     if ((rc = c->tok_off.ensure((R + 1) * sizeof(u64)))) return rc;
     if ((rc = c->chunk_off.ensure((R + 2) * sizeof(u64)))) return rc;
@@ -2238,84 +2427,25 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
         if ((rc = c->far_list.ensure((nT + 1) * sizeof(u32)))) return rc;
         if ((rc = c->g3list.ensure(g3_cap * sizeof(u64)))) return rc;
     }
-    hipStream_t st = c->stream;
-    u32* rec_lo = c->rec_lo.as<u32>();
-    u32 *tbytes = c->tile_bytes.as<u32>(), *ttoks = c->tile_toks.as<u32>(), *tflags = c->tile_flags.as<u32>();
-    u64* tile_base = c->tile_base.as<u64>();
-    u64 *den_off = c->den_off.as<u64>(), *tok_off = c->tok_off.as<u64>(), *chunk_off = c->chunk_off.as<u64>();
-    u64* totals = c->totals.as<u64>();
-    Plan* plan = c->plan.as<Plan>();
-    J* SA = c->SA.as<J>();
+    PathBufs B;
+    B.rec_lo = c->rec_lo.as<u32>();
+    B.SA = c->SA.as<J>(); B.seedJ = c->seedJ.as<J>(); B.seedS = c->seedS.as<S>();
+    B.far_list = c->far_list.as<u32>();
+    B.plan = c->plan.as<Plan>();
+    B.g3list = c->g3list.as<u64>(); B.g3_cap = g3_cap;
+    B.tile_bytes = c->tile_bytes.as<u32>(); B.tile_toks = c->tile_toks.as<u32>(); B.tile_flags = c->tile_flags.as<u32>();
+    B.packed = c->packed.as<u64>(); B.tile_base = c->tile_base.as<u64>();
+    B.partial = c->partial.as<u64>();
+    B.counts = c->counts.as<u64>();
+    B.totals = c->totals.as<u64>();
+    B.denoised = c->denoised.as<u8>();
+    B.den_off = c->den_off.as<u64>(); B.tok_off = c->tok_off.as<u64>(); B.chunk_off = c->chunk_off.as<u64>();
+    B.dropped = c->dropped.as<u8>();
+    B.tok_start = c->tok_start.as<u32>(); B.tok_len = c->tok_len.as<u32>();
+    B.chunks = c->chunks.as<ChunkDesc>(); B.chunk_cap = chunk_cap;
     drop_events(c);
-    HIPCHK(hipMemsetAsync(totals, 0, 16 * sizeof(u64), st));
-
-    {
-        Prof pr(c, "k_rec_lo");
-        hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + 2 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, rec_lo);
-    }
-    if (nT) {
-        if (!pass) {
-            u32* open_count = reinterpret_cast<u32*>(totals + 8);   // zeroed with the totals
-            { Prof pr(c, "k_seed");
-              const dim3 grid((unsigned)((nT + SEED_TPW * (NT / 64) - 1) / (SEED_TPW * (NT / 64))));
-              if (dc.normalize)
-                  hipLaunchKernelGGL(k_seed<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
-                                     c->seedJ.as<J>(), c->seedS.as<S>(), open_count);
-              else
-                  hipLaunchKernelGGL(k_seed<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
-                                     c->seedJ.as<J>(), c->seedS.as<S>(), open_count); }
-            // the next three return at once unless k_seed left tiles open
-            { Prof pr(c, "k_summary");
-              const dim3 grid((unsigned)std::min<u64>(nT, SUMMARY_GRID));
-              if (dc.normalize) hipLaunchKernelGGL(k_summary<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA);
-              else hipLaunchKernelGGL(k_summary<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA); }
-            { Prof pr(c, "k_tile_carry");
-              u32* far_count = reinterpret_cast<u32*>(totals + 7);   // zeroed with the totals
-              hipLaunchKernelGGL(k_tile_carry_near, dim3((unsigned)std::min<u64>((nT + 255) / 256, 1024)), dim3(256), 0, st, SA, nT,
-                                 open_count, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count);
-              hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 1024)), dim3(NT), 0, st,
-                                 SA, nT, c->seedJ.as<J>(), c->seedS.as<S>(), c->far_list.as<u32>(), far_count); }
-            { Prof pr(c, "k_plan");
-              if (dc.normalize)
-                  hipLaunchKernelGGL(k_plan<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
-                                     c->seedJ.as<J>(), c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes,
-                                     ttoks, tflags, c->plan_stop());
-              else
-                  hipLaunchKernelGGL(k_plan<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
-                                     c->seedJ.as<J>(), c->seedS.as<S>(), dc, plan, c->g3list.as<u64>(), g3_cap, totals + 6, tbytes,
-                                     ttoks, tflags, c->plan_stop()); }
-            { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
-                                 c->g3list.as<u64>(), totals + 6, g3_cap, tbytes, ttoks, totals); }
-        } else {
-            Prof pr(c, "k_count_tokens");
-            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, tbytes, ttoks,
-                               tflags);
-        }
-        { Prof pr(c, "scan_tiles");
-          hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, tbytes, ttoks, tflags, nT,
-                             c->packed.as<u64>());
-          if ((rc = scan_u64(c, c->packed.as<u64>(), nT, tile_base))) return rc; }
-        { Prof pr(c, "k_emit");
-          if (pass)
-              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
-                                 d_offsets, rec_lo, R, N, nB, nT, (const Plan*)nullptr, tile_base, (u8*)nullptr, c->tok_start.as<u32>(), c->tok_len.as<u32>(),
-                                 den_off, tok_off, c->emit_stop());
-          else
-              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
-                                 d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, c->denoised.as<u8>(), c->tok_start.as<u32>(), c->tok_len.as<u32>(),
-                                 den_off, tok_off, c->emit_stop()); }
-    }
-    { Prof pr(c, "k_finish_count");
-      hipLaunchKernelGGL(k_finish_count, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nT, rec_lo, R, N,
-                         pass ? 1 : 0, dc, den_off, tok_off, totals, c->counts.as<u64>(), c->dropped.as<u8>()); }
-    { Prof pr(c, "scan_chunks");
-      if ((rc = scan_u64(c, c->counts.as<u64>(), R, chunk_off))) return rc; }
-    { Prof pr(c, "k_chunk_emit");
-      hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, chunk_cap,
-                         c->chunks.as<ChunkDesc>(), totals); }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_totals, totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    if ((rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc))) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_totals, B.totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     c->pending.active = true;
     c->pending.d_bytes = d_bytes;
     c->pending.d_offsets = d_offsets;
@@ -2389,6 +2519,84 @@ static int collect_device(trp_ctx* c, trp_result* out) {
     c->last = *out;
     c->last_R = R;
     c->have_last = true;
+    return TRP_OK;
+}
+
+uint64_t trp_token_bound(uint64_t n_bytes, uint64_t n_records) { return token_bound(n_bytes, n_records); }
+
+// The path with every working array in this GPU's fixed scratch array and every result array the caller's: no
+// hipMalloc / hipFree / hipHostMalloc / event creation, here or in anything it calls.
+int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R,
+                                        uint64_t N, const trp_config* cfg, const trp_out_buffers* ob, trp_result* out) {
+    if (!c || !ob || !out) return fail(TRP_E_ARG, "ctx/buffers/out is null");
+    if (c->pending.active) return fail(TRP_E_ARG, "a batch is already in flight on this context");
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    if ((rc = check_batch_args(d_bytes, d_offsets, R, N))) return rc;
+    if (N > NOALLOC_MAX_BYTES) return fail(TRP_E_TOO_LARGE, "batch exceeds TRP_NOALLOC_MAX_BYTES: split it by record range");
+    if (R > NOALLOC_MAX_RECORDS) return fail(TRP_E_TOO_LARGE, "batch exceeds TRP_NOALLOC_MAX_RECORDS: split it by record range");
+    const bool pass = !dc.denoise_enabled;
+    if (!ob->denoised_offsets || !ob->tok_offsets || !ob->chunk_offsets || (R && !ob->dropped))
+        return fail(TRP_E_ARG, "a per-record output array is null");
+    if (!pass && N && (!ob->denoised || ob->denoised_cap < N))
+        return fail(TRP_E_ARG, "denoised buffer must hold n_bytes bytes");
+    if (((uintptr_t)ob->denoised & 15u) != 0) return fail(TRP_E_ARG, "denoised buffer must be 16-byte aligned");
+    if (N && (!ob->tok_start || !ob->tok_len || ob->tok_cap < token_bound(N, R)))
+        return fail(TRP_E_ARG, "token arrays must hold trp_token_bound(n_bytes, n_records) entries");
+    if (ob->chunk_cap && !ob->chunks) return fail(TRP_E_ARG, "chunks is null");
+    HIPCHK(hipSetDevice(c->device));
+    unsigned char* sp = c->scratch_ptr;   // never the array's name: that is not a device address on the host
+    if (!sp) return fail(TRP_E_HIP, "scratch array address unknown");
+    constexpr ScratchLayout L = scratch_layout();
+    PathBufs B;
+    B.totals = reinterpret_cast<u64*>(sp + L.totals);
+    B.rec_lo = reinterpret_cast<u32*>(sp + L.rec_lo);
+    B.SA = reinterpret_cast<J*>(sp + L.SA);
+    B.seedJ = reinterpret_cast<J*>(sp + L.seedJ);
+    B.seedS = reinterpret_cast<S*>(sp + L.seedS);
+    B.far_list = reinterpret_cast<u32*>(sp + L.far_list);
+    B.tile_bytes = reinterpret_cast<u32*>(sp + L.tile_bytes);
+    B.tile_toks = reinterpret_cast<u32*>(sp + L.tile_toks);
+    B.tile_flags = reinterpret_cast<u32*>(sp + L.tile_flags);
+    B.packed = reinterpret_cast<u64*>(sp + L.packed);
+    B.tile_base = reinterpret_cast<u64*>(sp + L.tile_base);
+    B.partial = reinterpret_cast<u64*>(sp + L.partial);
+    B.counts = reinterpret_cast<u64*>(sp + L.counts);
+    B.g3list = reinterpret_cast<u64*>(sp + L.g3list);
+    B.g3_cap = NOALLOC_G3_CAP;
+    B.plan = reinterpret_cast<Plan*>(sp + L.plan);
+    B.denoised = ob->denoised;
+    B.den_off = ob->denoised_offsets; B.tok_off = ob->tok_offsets; B.chunk_off = ob->chunk_offsets;
+    B.dropped = ob->dropped;
+    B.tok_start = ob->tok_start; B.tok_len = ob->tok_len;
+    B.chunks = reinterpret_cast<ChunkDesc*>(ob->chunks);
+    B.chunk_cap = ob->chunk_cap;
+    // per-kernel event pairs would have to be created: this entry point is never profiled
+    const bool was_profiling = c->profiling;
+    c->profiling = false;
+    rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc);   // starts by clearing the totals and counters
+    c->profiling = was_profiling;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_totals, B.totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));   // into pinned memory
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof(*out));
+    out->n_records = R;
+    out->n_denoised = c->h_totals[0];
+    out->n_tokens = c->h_totals[1];
+    out->n_chunks = c->h_totals[2];
+    if (!pass && N && c->h_totals[5])
+        return fail(TRP_E_TOO_LARGE, "more digit-heavy lines outside the in-tile solver than the fixed work list holds");
+    if (c->h_totals[3])
+        return fail(TRP_E_TOO_LARGE, "chunk descriptor buffer too small: " + std::to_string(c->h_totals[2]) + " needed");
+    out->denoised = pass ? const_cast<uint8_t*>(d_bytes) : ob->denoised;
+    out->denoised_offsets = ob->denoised_offsets;
+    out->dropped = ob->dropped;
+    out->tok_start = ob->tok_start;
+    out->tok_len = ob->tok_len;
+    out->tok_offsets = ob->tok_offsets;
+    out->chunks = ob->chunks;
+    out->chunk_offsets = ob->chunk_offsets;
     return TRP_OK;
 }
 

@@ -54,6 +54,14 @@ class _ChunkText(C.Structure):
     _fields_ = [("text", C.c_void_p), ("offsets", C.c_void_p), ("n_bytes", C.c_uint64)]
 
 
+class _OutBuffers(C.Structure):
+    _fields_ = [("denoised", C.c_void_p), ("denoised_cap", C.c_uint64), ("denoised_offsets", C.c_void_p),
+                ("dropped", C.c_void_p), ("tok_start", C.c_void_p), ("tok_len", C.c_void_p),
+                ("tok_cap", C.c_uint64), ("tok_offsets", C.c_void_p), ("chunks", C.c_void_p),
+                ("chunk_cap", C.c_uint64), ("chunk_offsets", C.c_void_p)]
+
+
+NOALLOC_MAX_BYTES, NOALLOC_MAX_RECORDS = 32 << 20, 1 << 19
 OUT_TEXT, OUT_TOKENS, OUT_CHUNKS, OUT_CHUNK_TEXT, OUT_ALL = 1, 2, 4, 8, 7
 
 
@@ -71,7 +79,7 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
            "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
            "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event", "trp_chunk_bodies_device", "trp_bm25_texts_device", "trp_preprocess_batch_select",
-           "trp_chunk_text_free"]
+           "trp_chunk_text_free", "trp_token_bound", "trp_preprocess_batch_device_noalloc"]
 
 _lib = None
 
@@ -121,6 +129,10 @@ def load_library():
     L.trp_chunk_section.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(_Config),
                                     C.POINTER(_Result)]
     L.trp_free.argtypes = [C.c_void_p]
+    L.trp_token_bound.restype = C.c_uint64
+    L.trp_token_bound.argtypes = [C.c_uint64, C.c_uint64]
+    L.trp_preprocess_batch_device_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                      C.POINTER(_Config), C.POINTER(_OutBuffers), C.POINTER(_Result)]
     L.trp_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.trp_get_profile.argtypes = [C.c_void_p, C.POINTER(_KernelTime), C.c_int]
     L.trp_head_tokens_text_device.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
@@ -431,6 +443,18 @@ class Context:
         res = _Result()
         _check(self._L.trp_preprocess_batch_device(self._h, d_bytes, d_offsets, n_records, n_bytes,
                                                    C.byref(cfg), C.byref(res)))
+        return DeviceResult(self, res)
+
+    def preprocess_batch_device_noalloc(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int,
+                                        denoiser: DenoiserConfig, strategy: ChunkingStrategy,
+                                        buffers: "_OutBuffers") -> DeviceResult:
+        """preprocess_batch_device that allocates nothing: the working arrays are the library's fixed scratch
+        array, the result arrays the caller's device buffers described by `buffers` (at most NOALLOC_MAX_BYTES
+        bytes and NOALLOC_MAX_RECORDS records per call; calls that overlap on one GPU race)."""
+        cfg = _make_cfg(denoiser, strategy)
+        res = _Result()
+        _check(self._L.trp_preprocess_batch_device_noalloc(self._h, d_bytes, d_offsets, n_records, n_bytes,
+                                                           C.byref(cfg), C.byref(buffers), C.byref(res)))
         return DeviceResult(self, res)
 
     def submit_batch_device(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int,
