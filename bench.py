@@ -28,23 +28,89 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
-# Algorithmic HBM bytes of each kernel per launch, as a function of the batch figures: what the kernel
-# has to read and write once given its role (N input bytes, D denoised bytes, T tokens, C chunks,
-# R records, P = N/2 bytes of plan bit planes).
+# Algorithmic HBM bytes of each kernel per launch: what the path has to move through that kernel once, from the
+# batch figures (N input bytes, D denoised bytes, T tokens, R records).  Passes the implementation chose to make
+# (the N/2 bytes of plan bit planes k_plan writes and k_emit reads back) do not count; "with_plan" is the same
+# with those bytes included, i.e. what the kernel really has to move as it is built.
 KERNEL_BYTES = {
     "k_summary": lambda s: s["N"],
-    "k_plan": lambda s: s["N"] + s["N"] // 2,
+    "k_plan": lambda s: s["N"],
     "k_gate3": lambda s: s["N"] // 8,
     "k_count_tokens": lambda s: s["N"],
-    "k_emit": lambda s: s["N"] + (s["N"] // 2 if s["enabled"] else 0) + (s["D"] if s["enabled"] else 0)
-    + 8 * s["T"] + 16 * (s["R"] + 1),
+    "k_emit": lambda s: s["N"] + (s["D"] if s["enabled"] else 0) + 8 * s["T"] + 16 * (s["R"] + 1),
 }
+PLAN_BYTES = {"k_plan": lambda s: s["N"] // 2, "k_emit": lambda s: s["N"] // 2 if s["enabled"] else 0}
 
 
 def path_algorithmic_bytes(s):
     """B_alg of the whole path: input read once, denoised bytes, token table, chunk descriptors, the
     four u64 offset arrays and the dropped flags."""
     return s["N"] + (s["D"] if s["enabled"] else 0) + 8 * s["T"] + 32 * s["C"] + 32 * (s["R"] + 1) + s["R"]
+
+
+def kernel_profile(ctx, step, nb, reps):
+    """Average duration of every kernel per launch (HIP events on the context's stream) over `reps` passes."""
+    ctx.set_profiling(True)
+    acc = {}
+
+    def collect():
+        for name, ms in ctx.profile():
+            acc[name] = acc.get(name, 0.0) + ms
+
+    for _ in range(reps):
+        step(collect)
+    ctx.set_profiling(False)
+    return {k: v / (reps * nb) for k, v in acc.items()}
+
+
+def roofline_of(kern, stats, nb, ms_per_step):
+    """Roofline object of the dominant kernel; stats are the totals of one pass over nb batches."""
+    per_launch = {k: (v // nb if k != "enabled" else v) for k, v in stats.items()}   # average batch
+    dominant = max(kern, key=kern.get)
+    dom_bytes = KERNEL_BYTES.get(dominant, lambda s: s["N"])(per_launch)
+    with_plan = dom_bytes + PLAN_BYTES.get(dominant, lambda s: 0)(per_launch)
+    achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
+    b_alg = path_algorithmic_bytes(stats)
+    return {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel_ms": round(kern[dominant], 4), "algorithmic_bytes": dom_bytes,
+            "frac_with_plan": round(with_plan / (kern[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "path_algorithmic_bytes": b_alg,
+            "path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
+
+
+def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup):
+    """One more single-GPU workload on the same context: timed like the headline one (blocking calls,
+    synchronize on both sides), then a profiled pass for the per-kernel durations."""
+    import torch
+
+    def step(after_batch=None):
+        d = t = c = 0
+        for d_bytes, d_offs, r, n in batches:
+            res = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
+            d, t, c = d + int(res.n_denoised), t + int(res.n_tokens), c + int(res.n_chunks)
+            if after_batch is not None:
+                after_batch()
+        return d, t, c
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    N, R, nb = sum(b[3] for b in batches), sum(b[2] for b in batches), len(batches)
+    ms = elapsed / steps * 1e3
+    stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled}
+    kern = kernel_profile(ctx, step, nb, 3)
+    return {"workload": workload, "value": round(N * steps / elapsed / 1e9, 2), "unit": "GB/s",
+            "ms_per_step": round(ms, 4), "steps": steps, "bytes": N, "records": R, "batches_per_step": nb,
+            "overlap_tokens": list(st.overlap_tokens),
+            "outputs": {"denoised_bytes": res[0], "tokens": res[1], "chunks": res[2]},
+            "roofline": roofline_of(kern, stats, nb, ms)}
 
 
 def main():
@@ -64,6 +130,9 @@ def main():
                          "trp_wait_batch) instead of timing blocking calls on one context")
     ap.add_argument("--host-path", action="store_true",
                     help="also time trp_preprocess_batch on host buffers (PCIe both ways included)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the other single-GPU workloads (configs C, D, E on one GPU, host-memory path) that "
+                         "the default one-GPU run reports next to the headline value")
     args = ap.parse_args()
 
     import numpy as np
@@ -211,27 +280,9 @@ def main():
     value = total_bytes * args.steps / elapsed / 1e9
 
     # ---- per-kernel durations (HIP events on the launch stream), dominant kernel roofline ----------
-    ctx.set_profiling(True)
-    acc = {}
-    reps = max(3, min(args.steps, 10))
-
-    def collect():
-        for name, ms in ctx.profile():
-            acc[name] = acc.get(name, 0.0) + ms
-
-    for _ in range(reps):
-        step(collect)
-    ctx.set_profiling(False)
-    kern = {k: v / (reps * nb) for k, v in acc.items()}   # per launch
-    dominant = max(kern, key=kern.get)
-    dom_bytes = KERNEL_BYTES.get(dominant, lambda s: s["N"])(per_launch)
-    achieved = dom_bytes / (kern[dominant] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel_ms": round(kern[dominant], 4), "algorithmic_bytes": dom_bytes,
-                "path_algorithmic_bytes": path_algorithmic_bytes(stats),
-                "path_frac": round(path_algorithmic_bytes(stats) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
+    kern = kernel_profile(ctx, step, nb, max(3, min(args.steps, 10)))
+    roofline = roofline_of(kern, stats, nb, ms_per_step)
+    dominant = roofline["kernel"]
     # HBM bytes per launch of the dominant kernel from the committed counter runs (tools/collect_profiles.sh),
     # used only when they were taken on this very workload
     tr = os.path.join(ROOT, "profiles", "traffic.json")
@@ -263,25 +314,73 @@ def main():
         "corpus_generation_s": round(gen_s, 2),
     }
 
-    # ---- the same batch handed over in host memory: H2D of the input and D2H of every result array -----
-    if args.host_path and rank == 0:
-        N, R = batches[0][3], batches[0][2]     # the first batch of the shard
+    # ---- the same batch handed over in host memory: H2D of the input, D2H of the selected result arrays ----
+    extras = (world == 1 and rank == 0 and args.config == "B" and not args.no_extras and not args.normalize
+              and not args.no_denoise and ctx2 is None and args.bytes is None)
+    if (args.host_path or extras) and rank == 0:
+        N0, R0 = batches[0][3], batches[0][2]     # the first batch of the shard
         pinned = torch.from_numpy(data).pin_memory()
         offs64 = np.ascontiguousarray(offs, dtype=np.uint64)
         L = T.load_library()
         cfg = T._make_cfg(den, st)
-        best = None
-        for _ in range(3):
-            r = T._Result()
-            t0 = time.perf_counter()
-            rc = L.trp_preprocess_batch(ctx._h, pinned.data_ptr(), offs64.ctypes.data, R, C.byref(cfg), C.byref(r))
-            dt = time.perf_counter() - t0
-            if rc != 0:
-                raise SystemExit("trp_preprocess_batch failed: %d" % rc)
-            L.trp_result_free(C.byref(r))
-            best = dt if best is None else min(best, dt)
-        out["host_path"] = {"value": round(N / best / 1e9, 3), "unit": "GB/s", "ms": round(best * 1e3, 2),
-                            "note": "pinned input, H2D + kernels + D2H of all result arrays, best of 3"}
+        masks = [("all arrays", T.OUT_ALL), ("chunk descriptors + chunk text", T.OUT_CHUNKS | T.OUT_CHUNK_TEXT)]
+        hp = {}
+        for label, mask in masks:
+            best = None
+            for _ in range(3):
+                r, ct = T._Result(), T._ChunkText()
+                t0 = time.perf_counter()
+                rc = L.trp_preprocess_batch_select(ctx._h, pinned.data_ptr(), offs64.ctypes.data, R0, C.byref(cfg), mask,
+                                                   C.byref(r), C.byref(ct) if mask & T.OUT_CHUNK_TEXT else None)
+                dt = time.perf_counter() - t0
+                if rc != 0:
+                    raise SystemExit("trp_preprocess_batch_select failed: %d" % rc)
+                L.trp_result_free(C.byref(r))
+                if mask & T.OUT_CHUNK_TEXT:
+                    L.trp_chunk_text_free(C.byref(ct))
+                best = dt if best is None else min(best, dt)
+            hp[label] = {"value": round(N0 / best / 1e9, 3), "unit": "GB/s", "ms": round(best * 1e3, 2)}
+        out["host_path"] = {"value": hp["all arrays"]["value"], "unit": "GB/s", "ms": hp["all arrays"]["ms"],
+                            "by_outputs": hp,
+                            "note": "pinned input in host memory, H2D + kernels + D2H of the selected result arrays "
+                                    "(the per-record arrays always come back), best of 3"}
+        del pinned
+        L.trp_trim_host_pool()
+
+    # ---- the other single-GPU workloads of BASELINE.json, same context, same timing rules ---------------
+    if extras:
+        ex = {}
+        keep_host = (data, offs)
+
+        def to_dev(dd, oo):
+            return (torch.from_numpy(dd).cuda(), torch.from_numpy(oo.astype(np.int64)).cuda(), int(len(oo) - 1), int(len(dd)))
+
+        dd, oo = corpusgen.config_c(4_000_000_000, 43, threads)
+        bt = [to_dev(dd, oo)]
+        del dd, oo
+        ex["C"] = run_extra(T, ctx, "C", "config C: 4.0e9 B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB",
+                            bt, den, st, 5, 2)
+        del bt
+        torch.cuda.empty_cache()
+        dd, oo = corpusgen.config_d(1_000_000_000, 44, threads)
+        bt = [to_dev(dd, oo)]
+        del dd, oo
+        wl = "config D: 1.0e9 B skewed lengths, half the bytes in 200 B and half in 1 MiB records"
+        ex["D"] = run_extra(T, ctx, "D", wl, bt, den, st, 5, 2)
+        ex["D_overlaps_64_256"] = run_extra(T, ctx, "D", wl, bt, den, T.ChunkingStrategy(overlap_tokens=[64, 256]), 5, 2)
+        del bt
+        torch.cuda.empty_cache()
+        bt = []
+        for i in range(2):
+            dd, oo = corpusgen.config_c(4_000_000_000, 45 + i, threads)
+            bt.append(to_dev(dd, oo))
+            del dd, oo
+        ex["E_1gpu"] = run_extra(T, ctx, "E", "config E on one GPU: the first 8.0e9 B of the 64e9 B corpus' shard 0 "
+                                 "(config-C generator, seeds 45, 46), 2 slices of 4e9 B per step", bt, den, st, 3, 1)
+        del bt
+        torch.cuda.empty_cache()
+        out["configs"] = ex
+        data, offs = keep_host
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.normalize:

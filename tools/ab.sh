@@ -3,7 +3,7 @@
 # Prints value (GB/s), ms per step and the per-kernel durations (HIP events) of every variant.
 ARGS="$1"; shift
 for lib in "$@"; do
-  TRIPLETS_AMD_LIB=$PWD/$lib timeout -k 10 300 python3 bench.py --no-cpu-baseline $ARGS > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$lib FAILED"; tail -5 gpurun_out/ab_tmp.err; exit 1; }
+  TRIPLETS_AMD_LIB=$PWD/$lib timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extras $ARGS > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$lib FAILED"; tail -5 gpurun_out/ab_tmp.err; exit 1; }
   python3 - "$lib" "$ARGS" <<'PY'
 import json,sys
 d=json.loads(open("gpurun_out/ab_tmp.json").read().strip().split("\n")[-1])

@@ -11,12 +11,12 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- \
-    python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/stats.log"
+    python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > "$OUT/bench.json" 2> "$OUT/stats.log"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/fetch" -o fetch -- \
-    python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/fetch.json" 2> "$OUT/fetch.log"
+    python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$OUT/fetch.json" 2> "$OUT/fetch.log"
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/write" -o write -- \
-    python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/write.json" 2> "$OUT/write.log"
+    python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > "$OUT/write.json" 2> "$OUT/write.log"
 python3 tools/pmc_summary.py --traffic "$OUT/fetch" "$OUT/write" "$OUT/traffic.json" > "$OUT/traffic.txt"
 python3 - "$OUT" <<'PY'
 import json, sys

@@ -8,7 +8,7 @@ SEL="gpu"
 timeout -k 10 600 python -u -m pytest tests -m gpu -k "$SEL" -x -q --timeout 300 --timeout-method thread > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
 tail -2 gpurun_out/t.log
 for c in B C D; do
-  timeout -k 10 150 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --config $c > gpurun_out/b$c.json 2> gpurun_out/b$c.err || { tail -5 gpurun_out/b$c.err; exit 1; }
+  timeout -k 10 150 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --config $c > gpurun_out/b$c.json 2> gpurun_out/b$c.err || { tail -5 gpurun_out/b$c.err; exit 1; }
   python - gpurun_out/b$c.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
