@@ -7,8 +7,9 @@
 //   SA[nT]                        per-tile forward summary (struct J) written by k_summary (fallback path)
 //   plan[nB] (4 x u64)            emit plan bit planes (struct Plan) written by k_plan / k_gate3
 //   g3list[]                      digit-heavy lines that k_plan could not solve inside a tile (position | flags)
-//   tile_bytes[nT], tile_toks[nT], tile_flags[nT]   emitted bytes / token starts per tile
-//   tile_base[nT+1]               exclusive prefix of (bytes | toks<<32)
+//   rec_lo_w[nW+2]               the same per 4 KiB sub-tile (nW = ceil(N/4096)): k_emit works one wavefront per sub-tile
+//   tile_bytes[nW], tile_toks[nW], tile_flags[nW]   emitted bytes / token starts per sub-tile
+//   tile_base[nW+1]               exclusive prefix of (bytes | toks<<32)
 //   denoised[D], tok_start[T], tok_len[T], *_offsets[R+1], chunks[C]   results
 //
 // Kernel sequence with the denoiser enabled:
@@ -42,6 +43,11 @@ using namespace trp;
 namespace {
 
 constexpr int NT = TILE_BLOCKS;   // threads per workgroup
+// k_emit works on sub-tiles: the 64 blocks (4 KiB) of one wavefront of a tile.  The emitted byte / token counts
+// and their scanned bases are kept per sub-tile.
+constexpr int SUB_BLOCKS = 64;
+constexpr int SUB = SUB_BLOCKS * BLOCK;
+constexpr int SUBS_PER_TILE = TILE_BLOCKS / SUB_BLOCKS;
 
 __device__ inline UniTables dev_tables() {
     UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
@@ -402,6 +408,8 @@ __device__ inline void tile_store(const TileRegs& r, u8* sb) {
     if (tid == 0) lds_store16(sb + 48, r.halo);                                  // last 16 bytes of block -1
     else if (tid == 1) lds_store16(sb + (TILE_BLOCKS + 1) * PAD_STRIDE, r.halo);
 }
+struct SubShared;
+__device__ inline PadBlk lane_block_sub(const SubShared& sh, int i);
 __device__ inline PadBlk lane_block(const TileShared& sh, int i) {
     PadBlk b = {sh.bytes + (i + 1) * PAD_STRIDE};
     return b;
@@ -529,16 +537,25 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
 // k_rec_lo: rec_lo[t] = number of records whose start offset is < t*TILE (t = 0..nT), and
 // rec_lo[nT+1] = number of records whose start offset is < N.
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u32* __restrict__ rec_lo) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > nT + 1) return;
-    u64 key = t <= nT ? t * (u64)TILE : N;
+// rec_lo_w: the same for sub-tiles (w = 0..nW, and rec_lo_w[nW+1] for N).
+__global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW, u32* __restrict__ rec_lo,
+                         u32* __restrict__ rec_lo_w) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 key;
+    u32* dst;
+    if (i <= nT + 1) { key = i <= nT ? i * (u64)TILE : N; dst = rec_lo + i; }
+    else {
+        i -= nT + 2;
+        if (i > nW + 1) return;
+        key = i <= nW ? i * (u64)SUB : N;
+        dst = rec_lo_w + i;
+    }
     u64 lo = 0, hi = R;
     while (lo < hi) {
         u64 mid = (lo + hi) >> 1;
         if (offsets[mid] < key) lo = mid + 1; else hi = mid;
     }
-    rec_lo[t] = (u32)lo;
+    *dst = (u32)lo;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1057,30 +1074,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
     sh.tokc[tid] = TOKC;
     __syncthreads();
-    bool prev_tok = tid > 0 && (sh.tokc[tid - 1] >> 63);
+    // The counts are kept per sub-tile (= per wavefront).  A token that runs into a sub-tile from the left is
+    // counted as a start by the sub-tile (k_pack_tiles takes it back, from the flags).
+    bool prev_tok = lane > 0 && (sh.tokc[tid - 1] >> 63);
     u64 TS = token_starts(TOKC, L.d.RS, prev_tok);
     u32 nb = popc(pl.C) + popc(PFX), ntk = popc(TS), nmk = popc(marks);
-    // workgroup sums
+    const bool last_tok = __shfl((int)(u32)(TOKC >> 63), 63, 64) != 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         nb += __shfl_down((int)nb, off, 64);
         ntk += __shfl_down((int)ntk, off, 64);
         nmk += __shfl_down((int)nmk, off, 64);
     }
-    if (lane == 0) { sh.red[0][wave] = nb; sh.red[1][wave] = ntk; sh.red[2][wave] = nmk; }
+    if (lane == 0) {
+        sh.red[2][wave] = nmk;
+        const u64 sub = t * (u64)SUBS_PER_TILE + (u64)wave;
+        if (sub * (u64)SUB < N) {
+            tile_bytes[sub] = nb;
+            tile_toks[sub] = ntk;
+            u32 f = 0;
+            if ((TOKC & 1ull) && !(L.d.LS & 1ull)) f |= TF_FIRST_CONT;
+            if (last_tok) f |= TF_LAST_TOK;
+            tile_flags[sub] = f;
+        }
+    }
     __syncthreads();
     u32 sm = 0;
     for (int w = 0; w < NT / 64; w++) sm += sh.red[2][w];
-    if (tid == 0) {
-        u32 sb = 0, st = 0;
-        for (int w = 0; w < NT / 64; w++) { sb += sh.red[0][w]; st += sh.red[1][w]; }
-        tile_bytes[t] = sb;
-        tile_toks[t] = st;
-        u32 f = 0;
-        if ((sh.tokc[0] & 1ull) && !(L.d.LS & 1ull)) f |= TF_FIRST_CONT;   // thread 0's own block
-        if (sh.tokc[TILE_BLOCKS - 1] >> 63) f |= TF_LAST_TOK;
-        tile_flags[t] = f;
-    }
     if (sm > 0) {   // uniform, rare: lines left for k_gate3_solve go to the global work list
         if (tid == 0) sh.g3base = atomicAdd(reinterpret_cast<unsigned long long*>(g3count), (unsigned long long)sm);
         u32 at = block_scan_excl_fwd((u32)popc(marks), U32Add(), 0u, 0u, sh.scan32, (u32*)nullptr);   // barriers inside
@@ -1100,7 +1120,6 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ u64 tokc[TILE_BLOCKS];
-    __shared__ u32 red[NT / 64];
     __shared__ RsShared rs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
@@ -1118,22 +1137,21 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
     Plan pl = plan_passthrough(L.c, L.d.V);
     tokc[tid] = pl.TOK;
     __syncthreads();
-    bool prev_tok = tid > 0 && (tokc[tid - 1] >> 63);
+    bool prev_tok = lane > 0 && (tokc[tid - 1] >> 63);   // counts per sub-tile, as in k_plan
     u32 ntk = popc(token_starts(pl.TOK, L.d.RS, prev_tok));
+    const bool last_tok = __shfl((int)(u32)(pl.TOK >> 63), 63, 64) != 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ntk += __shfl_down((int)ntk, off, 64);
-    if (lane == 0) red[wave] = ntk;
-    __syncthreads();
-    if (tid == 0) {
-        u32 st = 0;
-        for (int w = 0; w < NT / 64; w++) st += red[w];
-        u64 nv = N - tS < (u64)TILE ? N - tS : (u64)TILE;
-        tile_bytes[t] = (u32)nv;
-        tile_toks[t] = st;
-        u32 f = 0;
-        if ((tokc[0] & 1ull) && !(L.d.RS & 1ull)) f |= TF_FIRST_CONT;
-        if (tokc[TILE_BLOCKS - 1] >> 63) f |= TF_LAST_TOK;
-        tile_flags[t] = f;
+    if (lane == 0) {
+        const u64 sub = t * (u64)SUBS_PER_TILE + (u64)wave, sS = sub * (u64)SUB;
+        if (sS < N) {
+            tile_bytes[sub] = (u32)(N - sS < (u64)SUB ? N - sS : (u64)SUB);
+            tile_toks[sub] = ntk;
+            u32 f = 0;
+            if ((pl.TOK & 1ull) && !(L.d.RS & 1ull)) f |= TF_FIRST_CONT;
+            if (last_tok) f |= TF_LAST_TOK;
+            tile_flags[sub] = f;
+        }
     }
 }
 
@@ -1178,10 +1196,10 @@ __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* 
                     u64 m = below((int)hi_b) & ~below((int)lo_b);
                     u64 pre = (w == w0) ? (1ull << lo_b) : 0;
                     plan_or(plan, w, m, m, (pre && !first) ? pre : 0, (pre && first && rab) ? pre : 0);
-                    atomicAdd(&tile_bytes[w / TILE_BLOCKS], (u32)popc(m));
+                    atomicAdd(&tile_bytes[w / SUB_BLOCKS], (u32)popc(m));
                 }
-                if (!first || rab) atomicAdd(&tile_bytes[w0 / TILE_BLOCKS], 1u);
-                atomicAdd(&tile_toks[w0 / TILE_BLOCKS], 1u);
+                if (!first || rab) atomicAdd(&tile_bytes[w0 / SUB_BLOCKS], 1u);
+                atomicAdd(&tile_toks[w0 / SUB_BLOCKS], 1u);
                 first = false;
             });
 }
@@ -1256,9 +1274,9 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
                     if (g) {
                         const u64 wb = w0 + jj, sp = gm.gPSP[jj], nl = gm.gPNL[jj];
                         plan_or(plan, wb, g, g, sp, nl);
-                        atomicAdd(&tile_bytes[wb / TILE_BLOCKS], (u32)(popc(g) + popc(sp | nl)));
+                        atomicAdd(&tile_bytes[wb / SUB_BLOCKS], (u32)(popc(g) + popc(sp | nl)));
                         // token starts of this block: kept bytes whose predecessor is not kept
-                        atomicAdd(&tile_toks[wb / TILE_BLOCKS], (u32)popc(g & ~((g << 1) | prevg)));
+                        atomicAdd(&tile_toks[wb / SUB_BLOCKS], (u32)popc(g & ~((g << 1) | prevg)));
                     }
                     prevg = g >> 63;
                 }
@@ -1358,45 +1376,97 @@ __global__ void k_pack_tiles(const u32* __restrict__ tile_bytes, const u32* __re
 // ---------------------------------------------------------------------------------------------------
 // k_emit: stream compaction of the tile per its plan -> denoised bytes, token table, per-record offsets
 // ---------------------------------------------------------------------------------------------------
-struct EmitScan {
-    u32 nb, ntk, nte;   // emitted bytes, token starts, token ends
-    int lts;            // tile-relative byte position of the last token start so far, -1 none
-};
-constexpr u32 TOK_CAP = 9 * TILE_BLOCKS;   // tokens per tile staged in LDS (9 KiB at 256 blocks); the rest is stored directly
-struct EmitOp {
-    __device__ EmitScan operator()(const EmitScan& a, const EmitScan& b) const {
-        EmitScan r;
-        r.nb = a.nb + b.nb;
-        r.ntk = a.ntk + b.ntk;
-        r.nte = a.nte + b.nte;
-        r.lts = b.lts >= 0 ? b.lts : a.lts;
-        return r;
-    }
-};
+constexpr u32 TOK_CAP = 9 * SUB_BLOCKS;   // tokens per sub-tile staged in LDS; the rest is stored directly
 
 // four u32 that are only 4-byte aligned in memory
 struct __attribute__((packed, aligned(4))) Quad32 { u32 x, y, z, w; };
 struct Pair32 { u32 lo, hi; };   // two consecutive dwords at a 4-byte aligned address
 
+// ---- sub-tile staging (one wavefront, 64 blocks) ------------------------------------------------------
+// Same LDS layout as TileShared: block i of the sub-tile lives at (i + 1) * PAD_STRIDE.
+struct SubShared {
+    alignas(16) u8 bytes[(SUB_BLOCKS + 2) * PAD_STRIDE];
+};
+struct SubRs {
+    u64 w[SUB_BLOCKS + 1];
+};
+struct SubRegs {
+    uint4 v[SUB / 16 / 64];
+    uint4 halo;   // lane 0: the 16 bytes before the sub-tile; lane 1: the 16 bytes after it
+};
+__device__ inline void sub_load(const u8* __restrict__ g, u64 N, u64 sS, SubRegs& r) {
+    const int lane = threadIdx.x;
+    if (sS >= HALO && sS + SUB + HALO <= N) {
+        const uint4* src = reinterpret_cast<const uint4*>(g + sS);
+#pragma unroll
+        for (int k = 0; k < SUB / 16 / 64; k++) r.v[k] = src[k * 64 + lane];
+        r.halo = make_uint4(0, 0, 0, 0);
+        if (lane < 2) r.halo = *reinterpret_cast<const uint4*>(g + (lane == 0 ? sS - HALO : sS + SUB));
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < SUB / 16 / 64; k++) r.v[k] = load16_guarded(g, N, sS + (u64)(k * 64 + lane) * 16);
+    r.halo = make_uint4(0, 0, 0, 0);
+    if (lane == 0) { if (sS >= HALO) r.halo = load16_guarded(g, N, sS - HALO); }
+    else if (lane == 1) r.halo = load16_guarded(g, N, sS + SUB);
+}
+__device__ inline void sub_store(const SubRegs& r, u8* sb) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < SUB / 16 / 64; k++) {
+        const int c = k * 64 + lane;
+        lds_store16(sb + ((c >> 2) + 1) * PAD_STRIDE + (c & 3) * 16, r.v[k]);
+    }
+    if (lane == 0) lds_store16(sb + 48, r.halo);
+    else if (lane == 1) lds_store16(sb + (SUB_BLOCKS + 1) * PAD_STRIDE, r.halo);
+}
+// Record starts of sub-tile s: records [rec_lo_w[s], rec_lo_w[s+1]) start inside it (see rs_fetch / rs_store).
+__device__ inline u32 sub_rs_fetch(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 s,
+                                   RsFetch& f) {
+    const u32 r0 = rec_lo_w[s], r1 = rec_lo_w[s + 1];
+    const u64 r = (u64)r0 + threadIdx.x;
+    f.q = ~0u;
+    f.n = r1 - r0;
+    if (r <= r1 && r < R) f.q = (u32)offsets[r];
+    return r0;
+}
+__device__ inline void sub_rs_set(SubRs& rs, u64 q, u64 N, u64 sS) {
+    const u64 d = q - sS;
+    if (q < N && d <= (u64)SUB) atomicOr(reinterpret_cast<unsigned long long*>(&rs.w[d >> 6]), 1ull << (d & 63));
+}
+__device__ inline void sub_rs_store(const RsFetch& f, const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w,
+                                    u64 R, u64 N, u64 s, SubRs& rs) {
+    const u64 sS = s * (u64)SUB;
+    for (int i = threadIdx.x; i <= SUB_BLOCKS; i += 64) rs.w[i] = 0;
+    if (f.q != ~0u) sub_rs_set(rs, f.q, N, sS);
+    if (f.n >= 64) {   // crowded sub-tile: the rest of its records
+        const u64 r0 = rec_lo_w[s], r1 = (u64)r0 + f.n;
+        for (u64 r = r0 + 64 + threadIdx.x; r <= r1 && r < R; r += 64) sub_rs_set(rs, offsets[r], N, sS);
+    }
+}
+
+__device__ inline PadBlk lane_block_sub(const SubShared& sh, int i) {
+    PadBlk b = {sh.bytes + (i + 1) * PAD_STRIDE};
+    return b;
+}
+
 // Once the run copies are done the input image is dead; its space then holds the staged token table and
 // the per-block words the record-offset loop needs.
 struct EmitLate {
     u32 tokstage[TOK_CAP];
-    u64 cw[TILE_BLOCKS], pfx[TILE_BLOCKS], ts[TILE_BLOCKS];
-    u32 eb[TILE_BLOCKS], tb[TILE_BLOCKS];
+    u64 cw[SUB_BLOCKS], pfx[SUB_BLOCKS], ts[SUB_BLOCKS];
+    u32 eb[SUB_BLOCKS], tb[SUB_BLOCKS];
 };
-static_assert(sizeof(EmitLate) <= sizeof(TileShared), "late emit data must fit in the input image");
+static_assert(sizeof(EmitLate) <= sizeof(SubShared), "late emit data must fit in the input image");
 
 struct EmitShared {
-    TileShared tile;
-    alignas(16) u8 out[TILE + 64];   // output image of the tile (linear)
-    u64 tokc[TILE_BLOCKS];
-    EmitScan scan[NT / 64];
-    EmitScan total;
-    u64 cin_start;      // corpus position where the token that runs into this tile starts
-    u32 flags;          // bit0: the tile's first byte continues a token that started before the tile
-    RsShared rs;
+    SubShared tile;
+    // output image of the sub-tile (linear).  Before the first byte is copied into it, its space holds the
+    // record-start words (SubRs), which every lane has moved to registers by then.
+    alignas(16) u8 out[SUB + 64];
+    u64 cin_start;      // corpus position where the token that runs into this sub-tile starts
 };
+static_assert(sizeof(SubRs) <= SUB + 64, "record-start words must fit in the output image");
 
 // Position where the token covering byte tS-1 starts (the tile's first byte continues it).
 template <bool PASSTHROUGH>
@@ -1431,59 +1501,75 @@ __device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 
     }
 }
 
-// What a workgroup fetches from global memory for one tile; fetched for tile t+1 while tile t is processed.
+// What a wavefront fetches from global memory for one sub-tile; fetched for sub-tile s+1 while s is processed.
 struct EmitIn {
-    TileRegs regs;
+    SubRegs regs;
     Plan pl;
-    RsFetch rf;           // record starts inside the tile
-    u64 prev_w;           // lane 0: token bytes of the block before the tile
-    u32 prev_rec;         // lane 0: start of the last record before the tile
-    u64 next_w;           // last lane: token bytes of the block after the tile
-    u64 base;             // scanned output byte / token base of the tile
+    RsFetch rf;           // record starts inside the sub-tile
+    u32 rec0;             // first record that starts inside the sub-tile
+    u64 prev_w;           // lane 0: token bytes of the block before the sub-tile
+    u32 prev_rec;         // lane 0: start of the last record before the sub-tile
+    u64 next_w;           // last lane: token bytes of the block after the sub-tile
+    u64 base;             // scanned output byte / token base of the sub-tile
 };
 template <bool PASSTHROUGH>
 __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                  const u32* __restrict__ rec_lo, u64 R, const Plan* __restrict__ plan, const u64* __restrict__ tile_base, u64 N, u64 nB,
-                                  u64 t, EmitIn& in) {
-    const int tid = threadIdx.x;
-    const u64 b = t * (u64)TILE_BLOCKS + tid;
-    tile_load(bytes, N, t * (u64)TILE, in.regs);
-    const u32 r0 = rs_fetch(offsets, rec_lo, R, t, in.rf);
+                                  const u32* __restrict__ rec_lo_w, u64 R, const Plan* __restrict__ plan,
+                                  const u64* __restrict__ tile_base, u64 N, u64 nB, u64 s, EmitIn& in) {
+    const int lane = threadIdx.x;
+    const u64 b = s * (u64)SUB_BLOCKS + lane;
+    sub_load(bytes, N, s * (u64)SUB, in.regs);
+    const u32 r0 = sub_rs_fetch(offsets, rec_lo_w, R, s, in.rf);
+    in.rec0 = r0;
     Plan z = {0, 0, 0, 0};
     in.pl = z;
     if (!PASSTHROUGH && b < nB) in.pl = plan[b];
     in.prev_w = in.next_w = 0;
     in.prev_rec = 0;
-    if (tid == 0 && b > 0) {
+    if (lane == 0 && b > 0) {
         if (r0 > 0) in.prev_rec = (u32)offsets[r0 - 1];
         if (!PASSTHROUGH) in.prev_w = plan[b - 1].TOK & plan[b - 1].C;
     }
-    if (!PASSTHROUGH && tid == NT - 1 && b + 1 < nB) in.next_w = plan[b + 1].TOK & plan[b + 1].C;
-    in.base = tile_base[t];
+    if (!PASSTHROUGH && lane == 63 && b + 1 < nB) in.next_w = plan[b + 1].TOK & plan[b + 1].C;
+    in.base = tile_base[s];
 }
 
-constexpr int EMIT_TPW = 2;   // consecutive tiles per workgroup
+// Inclusive maximum over the lanes up to this one (values >= 0; same lane pattern as wave_incl_scan_add).
+__device__ inline u32 wave_incl_scan_max(u32 v) {
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// One wavefront per workgroup and sub-tile (4 KiB).  Nothing crosses wavefronts, so there are no workgroup
+// barriers: a wavefront only orders its own LDS traffic, and the waves of a CU drift apart and overlap each
+// other's load, compute and store phases.  (Several sub-tiles per wavefront with the loads of the next one in
+// flight were measured slower, 0.93 ms for one against 1.01 ms for eight on 1 GB of English text: fresh
+// wavefronts hide the load latency better than the registers a prefetch holds.)
 template <bool PASSTHROUGH>
-__global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
-                                              const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
-                                              u64 N, u64 nB, u64 nT, const Plan* __restrict__ plan,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_emit(const u8* __restrict__ bytes,
+                                              const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
+                                              u64 N, u64 nB, u64 nW, const Plan* __restrict__ plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
                                               u32* __restrict__ tok_start, u32* __restrict__ tok_len,
                                               u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
     __shared__ EmitShared sh;
-    const int tid = threadIdx.x;
-    const u64 t0 = (u64)blockIdx.x * EMIT_TPW;
+    const int tid = threadIdx.x;   // = lane
+    const u64 t = blockIdx.x;
+    SubRs& srs = *reinterpret_cast<SubRs*>(sh.out);
     EmitIn in;
-    emit_fetch<PASSTHROUGH>(bytes, offsets, rec_lo, R, plan, tile_base, N, nB, t0, in);
-#pragma unroll 1
-    for (int ti = 0; ti < EMIT_TPW; ti++) {
-    const u64 t = t0 + ti;
-    if (t >= nT) break;   // uniform
-    const u64 tS = t * (u64)TILE;
-    const u64 b = t * (u64)TILE_BLOCKS + tid;
-    tile_store(in.regs, sh.tile.bytes);
-    rs_store(in.rf, offsets, rec_lo, R, N, t, sh.rs);
-    const PadBlk blk = lane_block(sh.tile, tid);
+    emit_fetch<PASSTHROUGH>(bytes, offsets, rec_lo_w, R, plan, tile_base, N, nB, t, in);
+    const u32 rec0 = uni(in.rec0), rec_n = uni(in.rf.n);   // records [rec0, rec0 + rec_n) start in this sub-tile
+    {
+    const u64 tS = t * (u64)SUB;
+    const u64 b = t * (u64)SUB_BLOCKS + tid;
+    sub_store(in.regs, sh.tile.bytes);
+    sub_rs_store(in.rf, offsets, rec_lo_w, R, N, t, srs);
+    const PadBlk blk = lane_block_sub(sh.tile, tid);
     const u64 p = tS + (u64)tid * BLOCK;
     const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)BLOCK ? (N - p) : (u64)BLOCK);
     const u64 V = below(nvalid);
@@ -1491,75 +1577,72 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
     if (nvalid == 0) { Plan z = {0, 0, 0, 0}; pl = z; }
     const u64 prev_w = in.prev_w, prev_rec = in.prev_rec;
     bool edge_prev = false, edge_next = (in.next_w & 1ull) != 0;
-    const u64 tb64 = in.base;
-    __syncthreads();
-    const u64 RS = sh.rs.w[tid] & V;
-    const bool next_rs = !(p + BLOCK < N) || (sh.rs.w[tid + 1] & 1ull);
-    if (ti + 1 < EMIT_TPW && t + 1 < nT) emit_fetch<PASSTHROUGH>(bytes, offsets, rec_lo, R, plan, tile_base, N, nB, t + 1, in);
-    // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every tile after that phase
-    if (stop_after == 1) { __syncthreads(); continue; }
+    const u64 tb64 = (u64)uni((u32)in.base) | ((u64)uni((u32)(in.base >> 32)) << 32);   // the same in every lane
+    wave_lds_sync();
+    const u64 RS = srs.w[tid] & V;
+    const bool next_rs = !(p + BLOCK < N) || (srs.w[tid + 1] & 1ull);
+    wave_lds_sync();   // the record-start words are in registers: their space is the output image from here on
+    // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every sub-tile after that phase
+    if (stop_after == 1) return;
     if (PASSTHROUGH) {
         Cls c = {classify_ws_fast(blk, nvalid), 0, 0, 0, 0, 0, 0};
         pl = plan_passthrough(c, V);
         if (tid == 0 && b > 0) edge_prev = !byte_is_ws(blk, -1);
-        if (tid == NT - 1 && p + BLOCK < N) edge_next = !byte_is_ws(blk, BLOCK);
+        if (tid == 63 && p + BLOCK < N) edge_next = !byte_is_ws(blk, BLOCK);
     } else if (tid == 0) {
         edge_prev = (prev_w >> 63) != 0;
     }
     const u64 TOKC = pl.TOK & pl.C;
     const u64 PFX = (pl.PSP | pl.PNL) & pl.C;
-    sh.tokc[tid] = TOKC;
-    __syncthreads();
-    const bool prev_tok = tid > 0 ? (sh.tokc[tid - 1] >> 63) != 0 : edge_prev;
-    const bool next_tok = tid < NT - 1 ? (sh.tokc[tid + 1] & 1ull) != 0 : edge_next;
+    // the neighbours' edge bits through the cross-lane network
+    const u32 up = (u32)__shfl_up((int)(u32)(TOKC >> 63), 1, 64), down = (u32)__shfl_down((int)(u32)(TOKC & 1ull), 1, 64);
+    const bool prev_tok = tid > 0 ? up != 0 : edge_prev;
+    const bool next_tok = tid < 63 ? down != 0 : edge_next;
     const u64 TS = token_starts(TOKC, RS, prev_tok);
     const u64 TE = token_ends(TOKC, RS, next_tok, next_rs);
-    EmitScan me;
-    me.nb = popc(pl.C) + popc(PFX);
-    me.ntk = popc(TS);
-    me.nte = popc(TE);
-    me.lts = TS ? tid * BLOCK + top(TS) : -1;
-    EmitScan ident = {0, 0, 0, -1};
-    EmitScan seed = {(u32)(tb64 & 0xFFFFFFFFull), (u32)(tb64 >> 32), 0, -1};
-    EmitScan tot;
-    EmitScan ex = block_scan_excl_fwd(me, EmitOp(), ident, seed, sh.scan, &tot);
-    const u32 out0 = PASSTHROUGH ? (u32)tS : seed.nb;   // output position of the tile's first byte
-    const u32 tok0 = seed.ntk;                           // index of the first token that starts in the tile
+    // wave prefix sums: emitted bytes | token starts << 16, token ends; prefix maximum: last token start + 1
+    const u32 me_nb = popc(pl.C) + popc(PFX), me_ntk = popc(TS), me_nte = popc(TE);
+    const u32 me_a = me_nb | (me_ntk << 16);
+    const u32 inc_a = wave_incl_scan_add(me_a), inc_e = wave_incl_scan_add(me_nte);
+    const u32 inc_l = wave_incl_scan_max(TS ? (u32)(tid * BLOCK + top(TS) + 1) : 0u);
+    const u32 out0 = PASSTHROUGH ? (u32)tS : (u32)(tb64 & 0xFFFFFFFFull);   // output position of the sub-tile's first byte
+    const u32 tok0 = (u32)(tb64 >> 32);                                      // index of the first token that starts in it
+    const u32 ex_a = inc_a - me_a;
+    const u32 ex_nb = (PASSTHROUGH ? 0u : out0) + (ex_a & 0xFFFFu), ex_ntk = tok0 + (ex_a >> 16);
+    const u32 up_l = (u32)__shfl_up((int)inc_l, 1, 64);   // every lane takes part
+    const u32 ex_l = tid > 0 ? up_l : 0u;
+    const int ex_lts = (int)ex_l - 1;   // sub-tile-relative position of the last token start before this block, -1 none
+    const u32 tot_a = readlane_u32(inc_a, 63), tot_nte = readlane_u32(inc_e, 63);
+    const u32 total_nb = (PASSTHROUGH ? 0u : out0) + (tot_a & 0xFFFFu);
+    (void)inc_e;
     const u32 shift = PASSTHROUGH ? 0 : (out0 & 15u);
-    if (tid == 0) {
-        sh.total = tot;
-        // does a token run into this tile from the left?  Find where it starts.
-        sh.cin_start = 0;
-        sh.flags = 0;
-        if ((TOKC & 1ull) && prev_tok && !(RS & 1ull)) {
-            sh.flags = 1;
-            long long at = -1;   // start position inside the previous block, if it can be told from there
-            // the last record that starts before the tile, as a position in the previous block (or -1)
-            const long long rp = (prev_rec + 64 >= tS && prev_rec < tS) ? (long long)(prev_rec + 64 - tS) : -1;
-            if (PASSTHROUGH) {
-                for (int k = 1; k <= 12; k++) {
-                    if (rp == 64 - k) { at = 64 - k; break; }
-                    if (byte_is_ws(blk, -k - 1)) { at = 64 - k; break; }
-                }
-            } else {
-                u64 zeros = ~prev_w;   // bit 63 of prev_w is set
-                long long z = zeros ? top(zeros) + 1 : -1;
-                at = z > rp ? z : rp;
+    // does a token run into this sub-tile from the left?  Lane 0 finds where it starts.
+    const bool runs_in = readlane_u32((u32)(((TOKC & 1ull) && prev_tok && !(RS & 1ull)) ? 1u : 0u), 0) != 0;
+    if (tid == 0 && runs_in) {
+        long long at = -1;   // start position inside the previous block, if it can be told from there
+        // the last record that starts before the sub-tile, as a position in the previous block (or -1)
+        const long long rp = (prev_rec + 64 >= tS && prev_rec < tS) ? (long long)(prev_rec + 64 - tS) : -1;
+        if (PASSTHROUGH) {
+            for (int k = 1; k <= 12; k++) {
+                if (rp == 64 - k) { at = 64 - k; break; }
+                if (byte_is_ws(blk, -k - 1)) { at = 64 - k; break; }
             }
-            if (at >= 0) sh.cin_start = (b - 1) * 64 + (u64)at;
-            else {
-                sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, prev_rec);
-            }
+        } else {
+            u64 zeros = ~prev_w;   // bit 63 of prev_w is set
+            long long z = zeros ? top(zeros) + 1 : -1;
+            at = z > rp ? z : rp;
         }
+        if (at >= 0) sh.cin_start = (b - 1) * 64 + (u64)at;
+        else sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, prev_rec);
     }
-    if (stop_after == 2) { __syncthreads(); continue; }
+    if (stop_after == 2) return;
     // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes
     // with no separator inside; its source is contiguous in the lane's block and its destination is
     // contiguous in the output image, so it moves as (unaligned source, aligned destination) dwords.
     // Lanes start their runs at different dwords so that the stride-64 pattern spreads over the banks.
     if (!PASSTHROUGH) {
         const u8* src0 = blk.p;
-        u32 o = ex.nb - out0 + shift;
+        u32 o = ex_nb - out0 + shift;
         u64 Cm = pl.C;
         u64 brk = Cm & (PFX | ~(Cm << 1));
         while (brk) {
@@ -1601,36 +1684,36 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
             o += len;
         }
     }
-    __syncthreads();
-    if (stop_after == 3) { __syncthreads(); continue; }
-    // tokens: one (start, len) record per token end.  Tokens that start and end inside the tile are
+    wave_lds_sync();   // the input image is dead from here on, the output image and cin_start are complete
+    if (stop_after == 3) return;
+    // tokens: one (start, len) record per token end.  Tokens that start and end inside the sub-tile are
     // staged in LDS (the input image is no longer needed) and stored with coalesced writes below.
     EmitLate& late = *reinterpret_cast<EmitLate*>(sh.tile.bytes);
     u32* tokstage = late.tokstage;
     late.cw[tid] = pl.C;
     late.pfx[tid] = PFX;
     late.ts[tid] = TS;
-    late.eb[tid] = ex.nb;
-    late.tb[tid] = ex.ntk;
+    late.eb[tid] = ex_nb;
+    late.tb[tid] = ex_ntk;
     {
-        const bool plain = PASSTHROUGH || (pl.C == V && PFX == 0);   // output position = ex.nb + bit index
+        const bool plain = PASSTHROUGH || (pl.C == V && PFX == 0);   // output position = ex_nb + bit index
         auto outpos = [&](int j) -> u32 {   // output position of the (copied) byte at bit j
             if (PASSTHROUGH) return (u32)p + (u32)j;
-            if (plain) return ex.nb + (u32)j;
-            return ex.nb + popc(pl.C & below(j)) + popc(PFX & below(j + 1));
+            if (plain) return ex_nb + (u32)j;
+            return ex_nb + popc(pl.C & below(j)) + popc(PFX & below(j + 1));
         };
         auto put = [&](u32 idx, u32 start_out, u32 len, bool inside) {
             if (inside && idx - tok0 < TOK_CAP) tokstage[idx - tok0] = (start_out - out0) | (len << 16);
             else { tok_start[idx] = start_out; tok_len[idx] = len; }
         };
         u64 ts = TS, te = TE;
-        u32 idx = ex.ntk;   // index of the next token that starts in this block
+        u32 idx = ex_ntk;   // index of the next token that starts in this block
         if (te) {
             int x0 = ctz(te);
             if (!ts || x0 < ctz(ts)) {
                 // the token that runs into this block from the left ends at x0
-                bool inside = ex.lts >= 0;
-                u64 start_abs = inside ? tS + (u64)ex.lts : sh.cin_start;
+                bool inside = ex_lts >= 0;
+                u64 start_abs = inside ? tS + (u64)ex_lts : sh.cin_start;
                 u32 len = (u32)(p + x0 - start_abs + 1);
                 put(idx - 1, outpos(x0) - (len - 1), len, inside);
                 te &= te - 1;
@@ -1642,7 +1725,7 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
         const u32 slot0 = idx - tok0;
         if (slot0 + (u32)popc(ts) <= TOK_CAP) {
             u32* slot = tokstage + slot0;
-            const u32 base = PASSTHROUGH ? (u32)(p - tS) : ex.nb - out0;
+            const u32 base = PASSTHROUGH ? (u32)(p - tS) : ex_nb - out0;
             const u64 drops = PASSTHROUGH ? 0ull : ~pl.C;
             const u64 pfx = PASSTHROUGH ? 0ull : PFX;
             const u32 dl = (u32)drops, dh = (u32)(drops >> 32), ql = (u32)pfx, qh = (u32)(pfx >> 32);
@@ -1681,14 +1764,13 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     {
-        const bool starts_inside_token = (sh.flags & 1) != 0;
-        u32 n_ss = sh.total.nte - ((starts_inside_token && sh.total.nte > 0) ? 1u : 0u);
+        u32 n_ss = tot_nte - ((runs_in && tot_nte > 0) ? 1u : 0u);
         if (n_ss > TOK_CAP) n_ss = TOK_CAP;
         if (stop_after == 6) n_ss = 0;   // profiling aid: everything but the token table stores
         // four tokens per lane and store (the token arrays are only 4-byte aligned at tok0)
-        for (u32 i = tid * 4; i < n_ss; i += NT * 4) {
+        for (u32 i = tid * 4; i < n_ss; i += 64 * 4) {
             if (i + 4 <= n_ss) {
                 const uint4 v = *reinterpret_cast<const uint4*>(tokstage + i);
                 const Quad32 st = {out0 + (v.x & 0xFFFFu), out0 + (v.y & 0xFFFFu), out0 + (v.z & 0xFFFFu),
@@ -1705,12 +1787,13 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
             }
         }
     }
-    if (stop_after == 4) { __syncthreads(); continue; }
+    if (stop_after == 4) return;
     // per-record offsets
     {
-        u32 r0 = rec_lo[t], r1 = rec_lo[t + 1];
-        for (u64 r = (u64)r0 + tid; r < r1; r += NT) {
-            u64 q = offsets[r];
+        // lane i fetched the start of record rec0 + i with the sub-tile; a crowded sub-tile reads the rest
+        for (u32 k = (u32)tid; k < rec_n; k += 64) {
+            const u64 r = (u64)rec0 + k;
+            const u64 q = k < 64 ? (u64)in.rf.q : offsets[r];
             if (q >= N) continue;
             u32 l = (u32)((q - tS) >> 6), j = (u32)((q - tS) & 63);
             u64 lowm = below((int)j);
@@ -1718,36 +1801,40 @@ __global__ __launch_bounds__(NT) void k_emit(const u8* __restrict__ bytes,
             tok_off[r] = (u64)(late.tb[l] + popc(late.ts[l] & lowm));
         }
     }
-    if (stop_after == 5) { __syncthreads(); continue; }
+    if (stop_after == 5) return;
     // LDS output image -> global, 16-byte stores where the destination is aligned
     if (!PASSTHROUGH) {
-        const u32 n = sh.total.nb - out0;   // bytes this tile emits
+        const u32 n = total_nb - out0;   // bytes this sub-tile emits
         const u64 g0 = (u64)out0 - shift;   // 16-aligned
         const u32 end = shift + n;
-        for (u32 c16 = tid; c16 * 16 < end; c16 += NT) {
-            u32 lo = c16 * 16, hi = lo + 16;
-            const u8* src = sh.out + lo;
-            if (lo >= shift && hi <= end) {
-                *reinterpret_cast<uint4*>(denoised + g0 + lo) = *reinterpret_cast<const uint4*>(src);
-            } else {
-                for (u32 i = lo > shift ? lo : shift; i < hi && i < end; i++) denoised[g0 + i] = src[i - lo];
-            }
+        for (u32 c16 = tid; c16 * 16 < end; c16 += 64) {
+            const u32 lo = c16 * 16, hi = lo + 16;
+            if (lo >= shift && hi <= end)
+                *reinterpret_cast<uint4*>(denoised + g0 + lo) = *reinterpret_cast<const uint4*>(sh.out + lo);
+        }
+        // the partial chunks at the two ends, one byte per lane: lanes 0-15 the first chunk, lanes 16-31 the last
+        const u32 cl = (end - 1) >> 4;   // end > 0 whenever a lane gets here with something to do
+        if (tid < 16) {
+            const u32 i = (u32)tid;
+            if ((shift > 0 || end < 16) && i >= shift && i < end) denoised[g0 + i] = sh.out[i];
+        } else if (tid < 32) {
+            const u32 i = cl * 16 + (u32)tid - 16;
+            if (end > 0 && cl > 0 && (end & 15u) != 0 && i < end) denoised[g0 + i] = sh.out[i];
         }
     }
-    __syncthreads();   // the LDS images are reused by the next tile
     }
 }
 
 // Totals, the offsets of records that start at the very end of the corpus (k_emit only sees records that
 // start inside a tile), and per record: the number of chunks and the dropped flag.  One thread per entry
 // of the offset arrays (R + 1).
-__global__ void k_finish_count(const u64* __restrict__ tile_base, u64 nT, const u32* __restrict__ rec_lo, u64 R,
+__global__ void k_finish_count(const u64* __restrict__ tile_base, u64 nW, const u32* __restrict__ rec_lo_w, u64 R,
                                u64 N, int passthrough, DevCfg cfg, u64* __restrict__ den_off,
                                u64* __restrict__ tok_off, u64* __restrict__ totals, u64* __restrict__ counts,
                                u8* __restrict__ dropped) {
-    u64 D = nT ? (tile_base[nT] & 0xFFFFFFFFull) : 0, T = nT ? (tile_base[nT] >> 32) : 0;
+    u64 D = nW ? (tile_base[nW] & 0xFFFFFFFFull) : 0, T = nW ? (tile_base[nW] >> 32) : 0;
     if (passthrough) D = N;
-    const u64 first = rec_lo[nT + 1];   // first record whose start offset is >= N
+    const u64 first = rec_lo_w[nW + 1];   // first record whose start offset is >= N
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0) { totals[0] = D; totals[1] = T; }
     if (r > R) return;
@@ -1985,27 +2072,29 @@ constexpr u64 NOALLOC_MAX_BYTES = TRP_NOALLOC_MAX_BYTES, NOALLOC_MAX_RECORDS = T
 constexpr u64 NOALLOC_G3_CAP = NOALLOC_MAX_BYTES / 64;   // one listed digit-heavy line per 64 bytes of text
 
 struct ScratchLayout {
-    size_t totals, rec_lo, SA, seedJ, seedS, far_list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial,
+    size_t totals, rec_lo, rec_lo_w, SA, seedJ, seedS, far_list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial,
         counts, g3list, plan, end;
 };
 constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr ScratchLayout scratch_layout() {
     constexpr size_t nT = (NOALLOC_MAX_BYTES + TILE - 1) / TILE, nB = (NOALLOC_MAX_BYTES + BLOCK - 1) / BLOCK;
+    constexpr size_t nW = (NOALLOC_MAX_BYTES + SUB - 1) / SUB;
     constexpr size_t R = NOALLOC_MAX_RECORDS;
-    constexpr size_t nPart = ((nT > R ? nT : R) + NT * 8 - 1) / (NT * 8) + 1;
+    constexpr size_t nPart = ((nW > R ? nW : R) + NT * 8 - 1) / (NT * 8) + 1;
     ScratchLayout L = {};
     size_t at = 0;
     L.totals = at;     at = align256(at + 16 * sizeof(u64));
     L.rec_lo = at;     at = align256(at + (nT + 2) * sizeof(u32));
+    L.rec_lo_w = at;   at = align256(at + (nW + 2) * sizeof(u32));
     L.SA = at;         at = align256(at + (nT + 1) * sizeof(J));
     L.seedJ = at;      at = align256(at + (nT + 1) * sizeof(J));
     L.seedS = at;      at = align256(at + (nT + 1) * sizeof(S));
     L.far_list = at;   at = align256(at + (nT + 1) * sizeof(u32));
-    L.tile_bytes = at; at = align256(at + (nT + 1) * sizeof(u32));
-    L.tile_toks = at;  at = align256(at + (nT + 1) * sizeof(u32));
-    L.tile_flags = at; at = align256(at + (nT + 1) * sizeof(u32));
-    L.packed = at;     at = align256(at + (nT + 1) * sizeof(u64));
-    L.tile_base = at;  at = align256(at + (nT + 2) * sizeof(u64));
+    L.tile_bytes = at; at = align256(at + (nW + 1) * sizeof(u32));
+    L.tile_toks = at;  at = align256(at + (nW + 1) * sizeof(u32));
+    L.tile_flags = at; at = align256(at + (nW + 1) * sizeof(u32));
+    L.packed = at;     at = align256(at + (nW + 1) * sizeof(u64));
+    L.tile_base = at;  at = align256(at + (nW + 2) * sizeof(u64));
     L.partial = at;    at = align256(at + nPart * sizeof(u64));
     L.counts = at;     at = align256(at + (R + 1) * sizeof(u64));
     L.g3list = at;     at = align256(at + NOALLOC_G3_CAP * sizeof(u64));
@@ -2040,7 +2129,7 @@ struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;            // false: the caller's stream (trp_create_on_stream)
-    DevBuf rec_lo, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
+    DevBuf rec_lo, rec_lo_w, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
     DevBuf text, text_off, text_len;    // chunk text
@@ -2218,7 +2307,7 @@ void trp_destroy(trp_ctx* c) {
     if (c->aux) { trp_destroy(c->aux); c->aux = nullptr; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->rec_lo, &c->SA, &c->seedJ, &c->seedS, &c->plan,
+    DevBuf* bufs[] = {&c->rec_lo, &c->rec_lo_w, &c->SA, &c->seedJ, &c->seedS, &c->plan,
                       &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
@@ -2265,14 +2354,15 @@ __global__ void k_add_chunk_record(ChunkDesc* __restrict__ c, u64 n, u32 add) {
 struct PathBufs {
     // scratch
     u32* rec_lo;                  // nT + 2
+    u32* rec_lo_w;                // nW + 2
     J *SA, *seedJ;                // nT + 1 each
     S* seedS;                     // nT + 1
     u32* far_list;                // nT + 1
     Plan* plan;                   // nB + 1
     u64* g3list; u64 g3_cap;      // work list of digit-heavy lines
-    u32 *tile_bytes, *tile_toks, *tile_flags;   // nT + 1 each
-    u64 *packed, *tile_base;      // nT + 1, nT + 2
-    u64* partial;                 // scan_partials(max(nT, R))
+    u32 *tile_bytes, *tile_toks, *tile_flags;   // nW + 1 each (per sub-tile)
+    u64 *packed, *tile_base;      // nW + 1, nW + 2
+    u64* partial;                 // scan_partials(max(nW, R))
     u64* counts;                  // R + 1
     u64* totals;                  // 16
     // results
@@ -2293,7 +2383,7 @@ static u64 token_bound(u64 N, u64 R) { return (N + std::min<u64>(R, N)) / 2 + 4;
 static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uint8_t* d_bytes, const uint64_t* d_offsets,
                         uint64_t R, uint64_t N, const DevCfg& dc) {
     int rc;
-    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE;
+    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
     const bool pass = !dc.denoise_enabled;
     u32* rec_lo = B.rec_lo;
     u32 *tbytes = B.tile_bytes, *ttoks = B.tile_toks, *tflags = B.tile_flags;
@@ -2306,7 +2396,8 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
 
     {
         Prof pr(c, "k_rec_lo");
-        hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + 2 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, rec_lo);
+        hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + nW + 4 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, nW, rec_lo,
+                           B.rec_lo_w);
     }
     if (nT) {
         if (!pass) {
@@ -2348,21 +2439,21 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                tflags);
         }
         { Prof pr(c, "scan_tiles");
-          hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, tbytes, ttoks, tflags, nT,
+          hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, st, tbytes, ttoks, tflags, nW,
                              B.packed);
-          if ((rc = scan_u64_with(st, B.partial, B.packed, nT, tile_base))) return rc; }
+          if ((rc = scan_u64_with(st, B.partial, B.packed, nW, tile_base))) return rc; }
         { Prof pr(c, "k_emit");
           if (pass)
-              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
-                                 d_offsets, rec_lo, R, N, nB, nT, (const Plan*)nullptr, tile_base, (u8*)nullptr, B.tok_start, B.tok_len,
+              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
+                                 d_offsets, B.rec_lo_w, R, N, nB, nW, (const Plan*)nullptr, tile_base, (u8*)nullptr, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop());
           else
-              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)((nT + EMIT_TPW - 1) / EMIT_TPW)), dim3(NT), 0, st, d_bytes,
-                                 d_offsets, rec_lo, R, N, nB, nT, plan, tile_base, B.denoised, B.tok_start, B.tok_len,
+              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
+                                 d_offsets, B.rec_lo_w, R, N, nB, nW, plan, tile_base, B.denoised, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop()); }
     }
     { Prof pr(c, "k_finish_count");
-      hipLaunchKernelGGL(k_finish_count, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nT, rec_lo, R, N,
+      hipLaunchKernelGGL(k_finish_count, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nW, B.rec_lo_w, R, N,
                          pass ? 1 : 0, dc, den_off, tok_off, totals, B.counts, B.dropped); }
     { Prof pr(c, "scan_chunks");
       if ((rc = scan_u64_with(st, B.partial, B.counts, R, chunk_off))) return rc; }
@@ -2390,7 +2481,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if ((rc = check_batch_args(d_bytes, d_offsets, R, N))) return rc;
     HIPCHK(hipSetDevice(c->device));
     c->have_last = false;
-    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE;
+    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
     const bool pass = !dc.denoise_enabled;
     const u64 tok_cap = token_bound(N, R);
     u64 chunk_cap = chunk_bound(N, R, dc);
@@ -2403,12 +2494,13 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     u64 g3_cap = N / 256 + 4096;
     if (c->g3list.cap / sizeof(u64) > g3_cap) g3_cap = c->g3list.cap / sizeof(u64);
     if ((rc = c->rec_lo.ensure((nT + 2) * sizeof(u32)))) return rc;
-    if ((rc = c->tile_bytes.ensure((nT + 1) * sizeof(u32)))) return rc;
-    if ((rc = c->tile_toks.ensure((nT + 1) * sizeof(u32)))) return rc;
-    if ((rc = c->tile_flags.ensure((nT + 1) * sizeof(u32)))) return rc;
-    if ((rc = c->packed.ensure((nT + 1) * sizeof(u64)))) return rc;
-    if ((rc = c->tile_base.ensure((nT + 2) * sizeof(u64)))) return rc;
-    if ((rc = c->partial.ensure(scan_partials(std::max(nT, R)) * sizeof(u64)))) return rc;
+    if ((rc = c->rec_lo_w.ensure((nW + 2) * sizeof(u32)))) return rc;
+    if ((rc = c->tile_bytes.ensure((nW + 1) * sizeof(u32)))) return rc;
+    if ((rc = c->tile_toks.ensure((nW + 1) * sizeof(u32)))) return rc;
+    if ((rc = c->tile_flags.ensure((nW + 1) * sizeof(u32)))) return rc;
+    if ((rc = c->packed.ensure((nW + 1) * sizeof(u64)))) return rc;
+    if ((rc = c->tile_base.ensure((nW + 2) * sizeof(u64)))) return rc;
+    if ((rc = c->partial.ensure(scan_partials(std::max(nW, R)) * sizeof(u64)))) return rc;
     if ((rc = c->den_off.ensure((R + 1) * sizeof(u64)))) return rc;
     if ((rc = c->tok_off.ensure((R + 1) * sizeof(u64)))) return rc;
     if ((rc = c->chunk_off.ensure((R + 2) * sizeof(u64)))) return rc;
@@ -2429,6 +2521,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     }
     PathBufs B;
     B.rec_lo = c->rec_lo.as<u32>();
+    B.rec_lo_w = c->rec_lo_w.as<u32>();
     B.SA = c->SA.as<J>(); B.seedJ = c->seedJ.as<J>(); B.seedS = c->seedS.as<S>();
     B.far_list = c->far_list.as<u32>();
     B.plan = c->plan.as<Plan>();
@@ -2552,6 +2645,7 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
     PathBufs B;
     B.totals = reinterpret_cast<u64*>(sp + L.totals);
     B.rec_lo = reinterpret_cast<u32*>(sp + L.rec_lo);
+    B.rec_lo_w = reinterpret_cast<u32*>(sp + L.rec_lo_w);
     B.SA = reinterpret_cast<J*>(sp + L.SA);
     B.seedJ = reinterpret_cast<J*>(sp + L.seedJ);
     B.seedS = reinterpret_cast<S*>(sp + L.seedS);

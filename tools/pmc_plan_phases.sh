@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 for d in 1 2 3 4 5 6 0; do
   OUT=gpurun_out/pmc_pp$d
   rm -rf $OUT
-  TRP_PROFILE_PLAN_STOP=$d timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -f csv -d $OUT -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT.json 2> $OUT.log || exit 1
+  TRP_PROFILE_PLAN_STOP=$d timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -f csv -d $OUT -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > $OUT.json 2> $OUT.log || exit 1
   python3 - $OUT $d <<'PY'
 import csv,glob,sys
 from collections import defaultdict
