@@ -5,7 +5,9 @@
 //   rec_lo[nT+2]                  first record that starts at/after each tile start (+ one for N)
 //   seedJ[nT], seedS[nT]          what enters each tile from the left / right (k_seed, or k_tile_carry)
 //   SA[nT]                        per-tile forward summary (struct J) written by k_summary (fallback path)
-//   plan[nB] (4 x u64)            emit plan bit planes (struct Plan) written by k_plan / k_gate3
+//   plan: ct[nB] (2 x u64)        emit plan bit planes C and TOK of every block, written by k_plan / k_gate3
+//         px[nB] (2 x u64)        the planes PSP and PNL, only of the blocks that have or may get a separator
+//         pfx_mask[nW]            which blocks of a sub-tile those are (one bit per block)
 //   g3list[]                      digit-heavy lines that k_plan could not solve inside a tile (position | flags)
 //   rec_lo_w[nW+2]               the same per 4 KiB sub-tile (nW = ceil(N/4096)): k_emit works one wavefront per sub-tile
 //   tile_bytes[nW], tile_toks[nW], tile_flags[nW]   emitted bytes / token starts per sub-tile
@@ -948,6 +950,26 @@ __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool r
 
 struct U32Add { __device__ u32 operator()(u32 a, u32 b) const { return a + b; } };
 
+// The emit plan in global memory.  The copy and token planes exist for every block.  The separator planes
+// (PSP / PNL) are zero for most blocks of most corpora: they are stored only for the blocks that have a
+// separator bit, hold the marker of a digit-heavy line that is still to be solved, or lie inside such a line
+// (k_gate3_solve ORs the separators of the kept tokens into them); pfx_mask says which blocks those are.
+struct PlanCT { u64 C, TOK; };
+struct PlanPX { u64 PSP, PNL; };
+struct PlanMem {
+    PlanCT* ct;
+    PlanPX* px;
+    u64* pfx_mask;   // word s: blocks 64 s .. 64 s + 63
+};
+__host__ __device__ constexpr size_t plan_bytes(u64 nB) { return (nB + 1) * (sizeof(PlanCT) + sizeof(PlanPX)) + (nB / 64 + 2) * sizeof(u64); }
+__host__ __device__ inline PlanMem plan_view(void* base, u64 nB) {
+    PlanMem m;
+    m.ct = reinterpret_cast<PlanCT*>(base);
+    m.px = reinterpret_cast<PlanPX*>(m.ct + (nB + 1));
+    m.pfx_mask = reinterpret_cast<u64*>(m.px + (nB + 1));
+    return m;
+}
+
 struct PlanShared {
     TileShared tile;   // byte image; after classification reused for the eight G3Masks arrays
     J jscan[NT / 64];
@@ -968,7 +990,7 @@ template <bool NORMALIZE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
-                                              Plan* __restrict__ plan, u64* __restrict__ g3list, u64 g3cap,
+                                              PlanMem plan, u64* __restrict__ g3list, u64 g3cap,
                                               u64* __restrict__ g3count,
                                               u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
                                               u32* __restrict__ tile_flags, u32 stop_after) {
@@ -1016,8 +1038,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     }
     LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
+    bool head_g3 = false;   // the line that runs into this block is a digit-heavy line (marked at its first byte)
     Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
-                        : plan_block(L.c, L.d, k, cfg, unpack_ls8(own_head), unpack_ls8(own_tail));
+                        : plan_block(L.c, L.d, k, cfg, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -1068,7 +1091,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
     }
     if (stop_after == 5) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }
-    if (L.nvalid > 0) plan[b] = pl;
+    {
+        // separator planes: for blocks with a separator, with the marker of a line left for k_gate3_solve, or
+        // inside a digit-heavy line that began in an earlier block (k_gate3_solve may add separators there)
+        const bool need_px = L.nvalid > 0 && ((pl.PSP | pl.PNL) != 0 || marks != 0 || head_g3);
+        const u64 pm = __ballot(need_px);
+        if (L.nvalid > 0) {
+            const PlanCT ct = {pl.C, pl.TOK};
+            plan.ct[b] = ct;
+            if (need_px) { const PlanPX px = {pl.PSP, pl.PNL}; plan.px[b] = px; }
+        }
+        if (lane == 0 && (b >> 6) * (u64)SUB < N) plan.pfx_mask[b >> 6] = pm;
+    }
     if (stop_after == 6) return;
     u64 TOKC = pl.TOK;
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
@@ -1158,17 +1192,17 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
 // ---------------------------------------------------------------------------------------------------
 // k_gate3: solve the digit-heavy lines that k_plan marked (one lane per marked line, serial walk).
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void plan_or(Plan* plan, u64 word, u64 c, u64 tok, u64 psp, u64 pnl) {
-    if (c) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].C), c);
-    if (tok) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].TOK), tok);
-    if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PSP), psp);
-    if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&plan[word].PNL), pnl);
+__device__ inline void plan_or(const PlanMem& plan, u64 word, u64 c, u64 tok, u64 psp, u64 pnl) {
+    if (c) atomicOr(reinterpret_cast<unsigned long long*>(&plan.ct[word].C), c);
+    if (tok) atomicOr(reinterpret_cast<unsigned long long*>(&plan.ct[word].TOK), tok);
+    if (psp) atomicOr(reinterpret_cast<unsigned long long*>(&plan.px[word].PSP), psp);
+    if (pnl) atomicOr(reinterpret_cast<unsigned long long*>(&plan.px[word].PNL), pnl);
 }
 
 // Serial solver for one listed line (any length): lane-local walk over the bytes, results OR-ed into
 // the plan with atomics.
 __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* __restrict__ offsets, u64 R, u64 N,
-                                       const DevCfg& cfg, Plan* plan, u64 p, bool table, bool rab,
+                                       const DevCfg& cfg, const PlanMem& plan, u64 p, bool table, bool rab,
                                        u32* tile_bytes, u32* tile_toks) {
     const UniTables ut = dev_tables();
     ByteSrc src = make_src(bytes, N);
@@ -1213,7 +1247,7 @@ constexpr int G3S_LINES = 64 / G3_VIEW;             // lines per wavefront
 constexpr int G3S_STRIDE = 8 * (G3_VIEW + 1) + 1;   // u64 per line; odd, so that the lines spread over the banks
 __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes,
                                                      const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
-                                                     Plan* plan, const u64* __restrict__ list,
+                                                     PlanMem plan, const u64* __restrict__ list,
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
                                                      u32* tile_toks, u64* __restrict__ totals) {
     __shared__ u64 masks[G3S_LINES * G3S_STRIDE];
@@ -1264,8 +1298,8 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
             const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
             const bool ok = g3_lane_solve<G3_WORDS>(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio);
             const u64 mb = ~(1ull << (p & 63));   // the marker's flag bits
-            atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PSP), mb);
-            atomicAnd(reinterpret_cast<unsigned long long*>(&plan[w0].PNL), mb);
+            atomicAnd(reinterpret_cast<unsigned long long*>(&plan.px[w0].PSP), mb);
+            atomicAnd(reinterpret_cast<unsigned long long*>(&plan.px[w0].PNL), mb);
             if (ok) {
                 u64 prevg = 0;
 #pragma unroll 1
@@ -1376,7 +1410,6 @@ __global__ void k_pack_tiles(const u32* __restrict__ tile_bytes, const u32* __re
 // ---------------------------------------------------------------------------------------------------
 // k_emit: stream compaction of the tile per its plan -> denoised bytes, token table, per-record offsets
 // ---------------------------------------------------------------------------------------------------
-constexpr u32 TOK_CAP = 9 * SUB_BLOCKS;   // tokens per sub-tile staged in LDS; the rest is stored directly
 
 // four u32 that are only 4-byte aligned in memory
 struct __attribute__((packed, aligned(4))) Quad32 { u32 x, y, z, w; };
@@ -1450,14 +1483,9 @@ __device__ inline PadBlk lane_block_sub(const SubShared& sh, int i) {
     return b;
 }
 
-// Once the run copies are done the input image is dead; its space then holds the staged token table and
-// the per-block words the record-offset loop needs.
-struct EmitLate {
-    u32 tokstage[TOK_CAP];
-    u64 cw[SUB_BLOCKS], pfx[SUB_BLOCKS], ts[SUB_BLOCKS];
-    u32 eb[SUB_BLOCKS], tb[SUB_BLOCKS];
-};
-static_assert(sizeof(EmitLate) <= sizeof(SubShared), "late emit data must fit in the input image");
+// Once the run copies are done the input image is dead; its space then holds the staged token table: 17 tokens
+// per block on average (English text has 11); the tokens of a denser sub-tile beyond that are stored directly.
+constexpr u32 TOK_CAP = sizeof(SubShared) / sizeof(u32);
 
 struct EmitShared {
     SubShared tile;
@@ -1470,7 +1498,7 @@ static_assert(sizeof(SubRs) <= SUB + 64, "record-start words must fit in the out
 
 // Position where the token covering byte tS-1 starts (the tile's first byte continues it).
 template <bool PASSTHROUGH>
-__device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 N, const Plan* __restrict__ plan,
+__device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 N, const PlanCT* __restrict__ plan,
                                               u64 tS, u64 rec_start) {
     if (PASSTHROUGH) {
         u64 q = tS;   // bytes [q, tS) are token bytes
@@ -1511,10 +1539,11 @@ struct EmitIn {
     u32 prev_rec;         // lane 0: start of the last record before the sub-tile
     u64 next_w;           // last lane: token bytes of the block after the sub-tile
     u64 base;             // scanned output byte / token base of the sub-tile
+    u64 pfx;              // blocks of the sub-tile whose separator planes are stored
 };
 template <bool PASSTHROUGH>
 __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                  const u32* __restrict__ rec_lo_w, u64 R, const Plan* __restrict__ plan,
+                                  const u32* __restrict__ rec_lo_w, u64 R, const PlanMem& plan,
                                   const u64* __restrict__ tile_base, u64 N, u64 nB, u64 s, EmitIn& in) {
     const int lane = threadIdx.x;
     const u64 b = s * (u64)SUB_BLOCKS + lane;
@@ -1523,14 +1552,18 @@ __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __res
     in.rec0 = r0;
     Plan z = {0, 0, 0, 0};
     in.pl = z;
-    if (!PASSTHROUGH && b < nB) in.pl = plan[b];
+    in.pfx = 0;
+    if (!PASSTHROUGH) {
+        in.pfx = plan.pfx_mask[s];
+        if (b < nB) { const PlanCT ct = plan.ct[b]; in.pl.C = ct.C; in.pl.TOK = ct.TOK; }
+    }
     in.prev_w = in.next_w = 0;
     in.prev_rec = 0;
     if (lane == 0 && b > 0) {
         if (r0 > 0) in.prev_rec = (u32)offsets[r0 - 1];
-        if (!PASSTHROUGH) in.prev_w = plan[b - 1].TOK & plan[b - 1].C;
+        if (!PASSTHROUGH) in.prev_w = plan.ct[b - 1].TOK & plan.ct[b - 1].C;
     }
-    if (!PASSTHROUGH && lane == 63 && b + 1 < nB) in.next_w = plan[b + 1].TOK & plan[b + 1].C;
+    if (!PASSTHROUGH && lane == 63 && b + 1 < nB) in.next_w = plan.ct[b + 1].TOK & plan.ct[b + 1].C;
     in.base = tile_base[s];
 }
 
@@ -1553,7 +1586,7 @@ __device__ inline u32 wave_incl_scan_max(u32 v) {
 template <bool PASSTHROUGH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_emit(const u8* __restrict__ bytes,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
-                                              u64 N, u64 nB, u64 nW, const Plan* __restrict__ plan,
+                                              u64 N, u64 nB, u64 nW, PlanMem plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
                                               u32* __restrict__ tok_start, u32* __restrict__ tok_len,
                                               u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
@@ -1573,6 +1606,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     const u64 p = tS + (u64)tid * BLOCK;
     const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)BLOCK ? (N - p) : (u64)BLOCK);
     const u64 V = below(nvalid);
+    // the separator planes of the few blocks that have them: a second, dependent load, issued before the tile
+    // is stored to LDS
+    if (!PASSTHROUGH && ((in.pfx >> tid) & 1ull) && b < nB) { const PlanPX px = plan.px[b]; in.pl.PSP = px.PSP; in.pl.PNL = px.PNL; }
     Plan pl = in.pl;
     if (nvalid == 0) { Plan z = {0, 0, 0, 0}; pl = z; }
     const u64 prev_w = in.prev_w, prev_rec = in.prev_rec;
@@ -1633,7 +1669,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             at = z > rp ? z : rp;
         }
         if (at >= 0) sh.cin_start = (b - 1) * 64 + (u64)at;
-        else sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan, tS, prev_rec);
+        else sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan.ct, tS, prev_rec);
     }
     if (stop_after == 2) return;
     // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes
@@ -1688,13 +1724,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     if (stop_after == 3) return;
     // tokens: one (start, len) record per token end.  Tokens that start and end inside the sub-tile are
     // staged in LDS (the input image is no longer needed) and stored with coalesced writes below.
-    EmitLate& late = *reinterpret_cast<EmitLate*>(sh.tile.bytes);
-    u32* tokstage = late.tokstage;
-    late.cw[tid] = pl.C;
-    late.pfx[tid] = PFX;
-    late.ts[tid] = TS;
-    late.eb[tid] = ex_nb;
-    late.tb[tid] = ex_ntk;
+    u32* tokstage = reinterpret_cast<u32*>(sh.tile.bytes);
     {
         const bool plain = PASSTHROUGH || (pl.C == V && PFX == 0);   // output position = ex_nb + bit index
         auto outpos = [&](int j) -> u32 {   // output position of the (copied) byte at bit j
@@ -1790,15 +1820,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     if (stop_after == 4) return;
     // per-record offsets
     {
-        // lane i fetched the start of record rec0 + i with the sub-tile; a crowded sub-tile reads the rest
-        for (u32 k = (u32)tid; k < rec_n; k += 64) {
+        // lane i fetched the start of record rec0 + i with the sub-tile; a crowded sub-tile reads the rest.
+        // The record's block is another lane's: its words come through the cross-lane network (every lane takes
+        // part in every round).
+        for (u32 k0 = 0; k0 < rec_n; k0 += 64) {   // uniform
+            const u32 k = k0 + (u32)tid;
             const u64 r = (u64)rec0 + k;
-            const u64 q = k < 64 ? (u64)in.rf.q : offsets[r];
-            if (q >= N) continue;
-            u32 l = (u32)((q - tS) >> 6), j = (u32)((q - tS) & 63);
-            u64 lowm = below((int)j);
-            den_off[r] = PASSTHROUGH ? q : (u64)(late.eb[l] + popc(late.cw[l] & lowm) + popc(late.pfx[l] & lowm));
-            tok_off[r] = (u64)(late.tb[l] + popc(late.ts[l] & lowm));
+            const bool have = k < rec_n;
+            u64 q = k0 == 0 ? (u64)in.rf.q : 0;
+            if (k0 != 0 && have) q = offsets[r];
+            const bool live = have && q < N && q >= tS;
+            const u32 l = live ? (u32)((q - tS) >> 6) & 63u : 0u, j = (u32)((q - tS) & 63);
+            const u64 lowm = below((int)j);
+            const u32 eb = (u32)__shfl((int)ex_nb, (int)l, 64), tb = (u32)__shfl((int)ex_ntk, (int)l, 64);
+            const u64 cw = __shfl(pl.C, (int)l, 64), px = __shfl(PFX, (int)l, 64), ts = __shfl(TS, (int)l, 64);
+            if (live) {
+                den_off[r] = PASSTHROUGH ? q : (u64)(eb + popc(cw & lowm) + popc(px & lowm));
+                tok_off[r] = (u64)(tb + popc(ts & lowm));
+            }
         }
     }
     if (stop_after == 5) return;
@@ -2098,7 +2137,7 @@ constexpr ScratchLayout scratch_layout() {
     L.partial = at;    at = align256(at + nPart * sizeof(u64));
     L.counts = at;     at = align256(at + (R + 1) * sizeof(u64));
     L.g3list = at;     at = align256(at + NOALLOC_G3_CAP * sizeof(u64));
-    L.plan = at;       at = align256(at + (nB + 1) * sizeof(Plan));
+    L.plan = at;       at = align256(at + plan_bytes(nB));
     L.end = at;
     return L;
 }
@@ -2358,7 +2397,7 @@ struct PathBufs {
     J *SA, *seedJ;                // nT + 1 each
     S* seedS;                     // nT + 1
     u32* far_list;                // nT + 1
-    Plan* plan;                   // nB + 1
+    void* plan;                   // plan_bytes(nB): see PlanMem
     u64* g3list; u64 g3_cap;      // work list of digit-heavy lines
     u32 *tile_bytes, *tile_toks, *tile_flags;   // nW + 1 each (per sub-tile)
     u64 *packed, *tile_base;      // nW + 1, nW + 2
@@ -2390,7 +2429,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
     u64* tile_base = B.tile_base;
     u64 *den_off = B.den_off, *tok_off = B.tok_off, *chunk_off = B.chunk_off;
     u64* totals = B.totals;
-    Plan* plan = B.plan;
+    const PlanMem plan = plan_view(B.plan, nB);
     J* SA = B.SA;
     HIPCHK(hipMemsetAsync(totals, 0, 16 * sizeof(u64), st));
 
@@ -2445,7 +2484,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
         { Prof pr(c, "k_emit");
           if (pass)
               hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
-                                 d_offsets, B.rec_lo_w, R, N, nB, nW, (const Plan*)nullptr, tile_base, (u8*)nullptr, B.tok_start, B.tok_len,
+                                 d_offsets, B.rec_lo_w, R, N, nB, nW, plan, tile_base, (u8*)nullptr, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop());
           else
               hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
@@ -2512,7 +2551,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if ((rc = c->totals.ensure(16 * sizeof(u64)))) return rc;
     if (!pass) {
         if ((rc = c->SA.ensure((nT + 1) * sizeof(J)))) return rc;
-        if ((rc = c->plan.ensure((nB + 1) * sizeof(Plan)))) return rc;
+        if ((rc = c->plan.ensure(plan_bytes(nB)))) return rc;
         if ((rc = c->denoised.ensure(N + 64))) return rc;
         if ((rc = c->seedJ.ensure((nT + 1) * sizeof(J)))) return rc;
         if ((rc = c->seedS.ensure((nT + 1) * sizeof(S)))) return rc;
@@ -2524,7 +2563,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     B.rec_lo_w = c->rec_lo_w.as<u32>();
     B.SA = c->SA.as<J>(); B.seedJ = c->seedJ.as<J>(); B.seedS = c->seedS.as<S>();
     B.far_list = c->far_list.as<u32>();
-    B.plan = c->plan.as<Plan>();
+    B.plan = c->plan.p;
     B.g3list = c->g3list.as<u64>(); B.g3_cap = g3_cap;
     B.tile_bytes = c->tile_bytes.as<u32>(); B.tile_toks = c->tile_toks.as<u32>(); B.tile_flags = c->tile_flags.as<u32>();
     B.packed = c->packed.as<u64>(); B.tile_base = c->tile_base.as<u64>();
@@ -2659,7 +2698,7 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
     B.counts = reinterpret_cast<u64*>(sp + L.counts);
     B.g3list = reinterpret_cast<u64*>(sp + L.g3list);
     B.g3_cap = NOALLOC_G3_CAP;
-    B.plan = reinterpret_cast<Plan*>(sp + L.plan);
+    B.plan = sp + L.plan;
     B.denoised = ob->denoised;
     B.den_off = ob->denoised_offsets; B.tok_off = ob->tok_offsets; B.chunk_off = ob->chunk_offsets;
     B.dropped = ob->dropped;

@@ -809,9 +809,12 @@ TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
 
 // own_head / own_tail: the block's own statistics before its first and from its last line start on, as
 // lane_J computes them (head and tail of the block's summary).
+// *head_g3 (optional): the line that runs into the block from an earlier one is a digit-heavy line; it is
+// marked in the block that holds its first byte, nothing of it is planned here.
 TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg, const LineSum& own_head,
-                       const LineSum& own_tail) {
+                       const LineSum& own_tail, bool* head_g3 = nullptr) {
     Plan out = {0, 0, 0, 0};
+    bool head_pending = false;
     const bool head0 = !(d.LS & 1ull);      // the block starts inside a line begun earlier
     // Cell trimming of table rows (strip_table_pipes): a whitespace byte survives only when the
     // nearest non-whitespace byte on either side, within the line, is text (not a pipe).  The masks are
@@ -852,7 +855,7 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
                 out.TOK |= bit(s);
                 if (table) out.PSP |= bit(s);
                 if (rab) out.PNL |= bit(s);
-            }
+            } else head_pending = true;
         } else if (!table) {
             out.C |= d.LC & R;
             out.TOK |= d.LC & R & ~c.ws;
@@ -893,6 +896,7 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         line(s, R, false, range_sum(c, d, R));
     }
     plan_fold_prefixes(out, c.sp, c.nl, d.V);
+    if (head_g3) *head_g3 = head_pending;
     return out;
 }
 TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg) {
