@@ -690,7 +690,7 @@ struct SeedWave {
 };
 
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, u64 nT,
                                               u32 force_open, J* __restrict__ seedJ, S* __restrict__ seedS,
                                               u32* __restrict__ open_count) {

@@ -205,6 +205,7 @@ TOKENIZE = [
     (108, "alpha beta gamma", ["alpha", "beta", "gamma"]),
     (121, "東京\u3000大阪", ["東京", "大阪"]),
     (130, "one two three four", ["one", "two", "three", "four"]),
+    (139, "", []),
     (144, "  \t\n ", []),
     (149, "word", ["word"]),
     (181, "x y", ["x", "y"]),
@@ -257,18 +258,18 @@ CHUNK = [
 # (examples/common/example_sources.rs:211-243; demo config src/example_apps.rs:575-583:
 # default chunking, no denoiser).  Data files of the reference, copied as fixture data.
 EXAMPLE_DATASET = {
-    "source_a/2025-01-01/article_a.txt": "Source A Article A. This sample discusses market breadth and trend persistence for demonstration.\n",
-    "source_a/2025-01-02/article_b.txt": "Source A Article B. This sample discusses valuation compression and expected return dispersion.\n",
-    "source_b/2025-01-01/qa_alpha.txt": "What is alpha? Alpha is risk-adjusted excess return above a benchmark.\n",
-    "source_b/2025-01-03/qa_beta.txt": "What is beta? Beta describes sensitivity to broad market movement.\n",
-    "source_c/2025-01-02/logistics_a.txt": "Port Throughput Snapshot. Container dwell times improved while rail throughput stayed stable.\n",
-    "source_c/2025-01-04/logistics_b.txt": "Carrier Reliability Update. On-time departures increased and congestion normalized across lanes.\n",
-    "source_d/2025-01-01/industry_a.txt": "Industry Index Note. Segment growth accelerated due to software automation and pricing discipline.\n",
-    "source_d/2025-01-02/industry_b.txt": "Industry Margin Note. Input costs fell while utilization improved across production facilities.\n",
-    "source_e/2025-01-02/company_a.txt": "Company Brief A. Revenue quality improved with better retention and lower churn.\n",
-    "source_e/2025-01-05/company_b.txt": "Company Brief B. Cash conversion strengthened due to inventory normalization and faster collections.\n",
-    "source_f/2025-01-03/research_a.txt": "Research Summary A. Forecast uncertainty narrowed after updated policy guidance.\n",
-    "source_f/2025-01-06/research_b.txt": "Research Summary B. Scenario analysis shows asymmetric upside under lower financing costs.\n",
+    "source_a/2025-01-01/article_a.txt": "Source A Article A. This sample discusses market breadth and trend persistence for demonstration.",
+    "source_a/2025-01-02/article_b.txt": "Source A Article B. This sample discusses valuation compression and expected return dispersion.",
+    "source_b/2025-01-01/qa_alpha.txt": "What is alpha? Alpha is risk-adjusted excess return above a benchmark.",
+    "source_b/2025-01-03/qa_beta.txt": "What is beta? Beta describes sensitivity to broad market movement.",
+    "source_c/2025-01-02/logistics_a.txt": "Port Throughput Snapshot. Container dwell times improved while rail throughput stayed stable.",
+    "source_c/2025-01-04/logistics_b.txt": "Carrier Reliability Update. On-time departures increased and congestion normalized across lanes.",
+    "source_d/2025-01-01/industry_a.txt": "Industry Index Note. Segment growth accelerated due to software automation and pricing discipline.",
+    "source_d/2025-01-02/industry_b.txt": "Industry Margin Note. Input costs fell while utilization improved across production facilities.",
+    "source_e/2025-01-02/company_a.txt": "Company Brief A. Revenue quality improved with better retention and lower churn.",
+    "source_e/2025-01-05/company_b.txt": "Company Brief B. Cash conversion strengthened due to inventory normalization and faster collections.",
+    "source_f/2025-01-03/research_a.txt": "Research Summary A. Forecast uncertainty narrowed after updated policy guidance.",
+    "source_f/2025-01-06/research_b.txt": "Research Summary B. Scenario analysis shows asymmetric upside under lower financing costs.",
 }
 
 

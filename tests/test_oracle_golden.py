@@ -173,3 +173,18 @@ def test_multithreaded_batch_matches_single():
     for k in ("denoised", "denoised_offsets", "dropped", "tok_start", "tok_len", "tok_offsets",
               "chunks", "chunk_offsets"):
         assert (getattr(a, k) == getattr(b, k)).all(), k
+
+
+def test_fixtures_match_the_reference_test_source():
+    """In the build container (where the reference checkout exists) every fixture string is looked up, as text,
+    in the `#[test]` function it cites; elsewhere there is nothing to compare with."""
+    import importlib.util
+    root = "/root/reference"
+    if not os.path.isdir(os.path.join(root, "src")):
+        pytest.skip("reference checkout not present")
+    spec = importlib.util.spec_from_file_location("verify_against_reference",
+                                                  os.path.join(G, "verify_against_reference.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    problems, checked, modes = mod.verify(root)
+    assert checked > 200 and not problems, "\n".join(problems)
