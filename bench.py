@@ -80,6 +80,40 @@ def roofline_of(kern, stats, nb, ms_per_step):
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
 
 
+def run_in_flight(T, device, batches, den, st, steps, warmup):
+    """The same passes with one batch in flight on each of two contexts (trp_submit_batch_device /
+    trp_wait_batch): the kernels of consecutive batches overlap, the way a consumer of one batch overlaps with
+    the production of the next.  Every batch of every pass is waited for inside the timed region."""
+    import torch
+    cs = (T.Context(device), T.Context(device))
+
+    def passes(k):
+        busy, i = [False, False], 0
+        for _ in range(k):
+            for d_bytes, d_offs, r, n in batches:
+                j = i % 2
+                if busy[j]:
+                    cs[j].wait_batch()
+                cs[j].submit_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
+                busy[j] = True
+                i += 1
+        for j in (0, 1):
+            if busy[j]:
+                cs[j].wait_batch()
+
+    passes(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    passes(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    for c in cs:
+        c.close()
+    N = sum(b[3] for b in batches)
+    return {"value": round(N * steps / elapsed / 1e9, 2), "unit": "GB/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "steps": steps, "calls": "submit/wait, one batch in flight on each of two contexts"}
+
+
 def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup):
     """One more single-GPU workload on the same context: timed like the headline one (blocking calls,
     synchronize on both sides), then a profiled pass for the per-kernel durations."""
@@ -120,7 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=None,
                     help="bytes per GPU (default 1e9); with --config E the bytes of the whole corpus (default 64e9)")
-    ap.add_argument("--config", default="B", choices=["B", "C", "D", "E"])
+    ap.add_argument("--config", default="B", choices=["B", "C", "D", "E", "W"])
     ap.add_argument("--no-denoise", action="store_true")
     ap.add_argument("--normalize", action="store_true",
                     help="time normalize_inline_whitespace (the step before the path) instead of the path")
@@ -179,13 +213,17 @@ def main():
                     "%d slice(s) of <= 4e9 B per shard" % (total, n_slices))
     else:
         nbytes = args.bytes or 1_000_000_000
-        seed = {"B": 42, "C": 43, "D": 44}[args.config] + 1000 * rank
+        seed = {"B": 42, "C": 43, "D": 44, "W": 46}[args.config] + 1000 * rank
         if args.config == "B":
             data, offs = corpusgen.config_b(nbytes, seed, threads)
             workload = "config B: %.1e B synthetic ASCII English, records 3072-5120 B" % nbytes
         elif args.config == "C":
             data, offs = corpusgen.config_c(nbytes, seed, threads)
             workload = "config C: %.1e B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB" % nbytes
+        elif args.config == "W":
+            data, offs = corpusgen.config_w(nbytes, seed, threads)
+            workload = ("config C with wide scripts: %.1e B, half of the multibyte words Georgian / Ethiopic / Bengali / "
+                        "Tamil / Armenian / Khmer / Tibetan / Cherokee (per-character classifier path)" % nbytes)
         else:
             data, offs = corpusgen.config_d(nbytes, seed, threads)
             workload = "config D: %.1e B skewed lengths, half the bytes in 200 B and half in 1 MiB records" % nbytes
@@ -351,6 +389,7 @@ def main():
     if extras:
         ex = {}
         keep_host = (data, offs)
+        out["in_flight"] = run_in_flight(T, device, batches, den, st, max(args.steps, 10), 3)
 
         def to_dev(dd, oo):
             return (torch.from_numpy(dd).cuda(), torch.from_numpy(oo.astype(np.int64)).cuda(), int(len(oo) - 1), int(len(dd)))
@@ -368,6 +407,14 @@ def main():
         wl = "config D: 1.0e9 B skewed lengths, half the bytes in 200 B and half in 1 MiB records"
         ex["D"] = run_extra(T, ctx, "D", wl, bt, den, st, 5, 2)
         ex["D_overlaps_64_256"] = run_extra(T, ctx, "D", wl, bt, den, T.ChunkingStrategy(overlap_tokens=[64, 256]), 5, 2)
+        del bt
+        torch.cuda.empty_cache()
+        dd, oo = corpusgen.config_w(1_000_000_000, 46, threads)
+        bt = [to_dev(dd, oo)]
+        del dd, oo
+        ex["C_wide_scripts"] = run_extra(T, ctx, "W", "config C generator, 1.0e9 B, with half of the multibyte words in "
+                                         "scripts the classifier settles per character (Georgian, Ethiopic, Bengali, "
+                                         "Tamil, Armenian, Khmer, Tibetan, Cherokee)", bt, den, st, 5, 2)
         del bt
         torch.cuda.empty_cache()
         bt = []

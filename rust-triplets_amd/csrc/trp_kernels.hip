@@ -1046,12 +1046,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
     u64 marks = pl.TOK & ~pl.C;
     pl.TOK &= pl.C;
+    // most tiles of ordinary text have no digit-heavy line at all: one ballot per wave tells
     {
+        const u64 bm = __ballot(marks != 0);
+        if (lane == 0) sh.red[0][wave] = bm != 0 ? 1u : 0u;
+    }
+    __syncthreads();   // also: nobody reads the byte image any more
+    u32 any_marks = 0;
+    for (int w = 0; w < NT / 64; w++) any_marks |= sh.red[0][w];
+    if (any_marks) {   // uniform
         u64* base = reinterpret_cast<u64*>(sh.tile.bytes);
         G3Masks gm = {base, base + TILE_BLOCKS, base + 2 * TILE_BLOCKS, base + 3 * TILE_BLOCKS,
                       base + 4 * TILE_BLOCKS, base + 5 * TILE_BLOCKS, base + 6 * TILE_BLOCKS,
                       base + 7 * TILE_BLOCKS};
-        // the scans above ended with a barrier: nobody reads the byte image any more
         gm.ws[tid] = L.c.ws; gm.pipe[tid] = L.c.pipe; gm.dig[tid] = L.c.dig; gm.alp[tid] = L.c.alp;
         gm.ls[tid] = L.d.LS;
         gm.G[tid] = 0; gm.gPSP[tid] = 0; gm.gPNL[tid] = 0;

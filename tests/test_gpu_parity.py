@@ -293,6 +293,25 @@ def test_one_byte_records_fill_the_token_table(T, ctx):
         assert_same(exp, ctx.normalize_batch(data, offs), None, "one-byte records, normalize")
 
 
+def test_token_density_around_the_staged_table_of_a_sub_tile(T, ctx):
+    """k_emit stages the tokens of a 4 KiB sub-tile in LDS up to a fixed number and stores the rest directly:
+    token densities below, at and above that number, tokens that straddle every sub-tile edge (word lengths
+    that do not divide 4096), a token longer than several sub-tiles between dense stretches, many records per
+    sub-tile and records that end exactly on sub-tile edges; denoiser on and off, and normalize mode."""
+    import test_normalize as TN
+    dense = [b"a b " * 5000, b"ab cd " * 4000, b"abc def " * 3000, b"abcd efg " * 2500, b"abcdefg hi " * 2000]
+    mixed = [(b"w " * 1500 + b"longtoken" * 1500 + b" x y z " + b"q" * 4096 + b" " + b"r s " * 900)]
+    edges = [b"ab " * 1365 + b"c", b"d" * 4096, b"e f " * 1024, b"", b"g" * 4095 + b" ", b"h i"] * 3
+    crowded = [b"k l"] * 5000 + [b"m" * 70] * 300 + [b"n o p q\n12 34 56 ab\n"] * 2000
+    for recs in (dense, mixed, edges, crowded, dense + mixed + edges + crowded):
+        for cfg in ((True, 0.35, True, 16, (4, 2), 8), (False, 0.35, True, 1024, (64,), 512)):
+            exp, got = _run(T, ctx, recs, cfg)
+            assert_same(exp, got, recs, "token density, denoiser %s" % cfg[0])
+        norm, exp = TN.expected(recs)
+        data, offs = O.pack(recs)
+        assert_same(exp, ctx.normalize_batch(data, offs), recs, "token density, normalize")
+
+
 def test_inputs_produced_on_the_callers_stream_need_no_sync(T):
     """A context created on the caller's stream (here torch's current stream) is ordered after the
     asynchronous copies that produce its inputs; a context with a private stream gets the same ordering

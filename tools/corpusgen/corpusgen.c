@@ -11,6 +11,9 @@
  *                 numeric-only, 10 % GFM table rows (header / separator / data), 5 % blank, 5 %
  *                 symbol-only, 5 % other; 5 % of all lines end with CRLF.
  *   kind 2 ("D")  kind-0 prose with 20 % kind-1 lines (used for the skewed-length configuration).
+ *   kind 3 ("W")  kind 1 with half of the multi-byte words taken from scripts that the GPU classifier has no
+ *                 bit-plane rule for (Georgian, Ethiopic, Bengali, Tamil, Armenian, Khmer, Tibetan, Cherokee):
+ *                 every such character goes through the per-character table path.
  *
  * Record r is generated from splitmix64 seeded with seed ^ (r+1)*0x9E3779B97F4A7C15 and depends on
  * nothing else, so any record range can be produced independently (sharding, threads).
@@ -41,6 +44,9 @@ static const char* MB_WORDS[] = {"Société", "Ünternehmen", "año", "façade",
                                  "прибыль", "рынок", "北京工业有限公司", "東京", "収益", "市场", "🚀", "🌏",
                                  "naïve", "Ελλάδα", "доход"};
 #define N_MB (sizeof(MB_WORDS) / sizeof(MB_WORDS[0]))
+static const char* WIDE_WORDS[] = {"საქართველო", "ბაზარი", "ኢትዮጵያ", "ገበያ", "বাংলা", "বাজার", "தமிழ்", "சந்தை",
+                                   "հայերեն", "շուկա", "ខ្មែរ", "བོད་ཡིག", "ᏣᎳᎩ", "ગુજરાતી", "ਪੰਜਾਬੀ", "മലയാളം"};
+#define N_WIDE (sizeof(WIDE_WORDS) / sizeof(WIDE_WORDS[0]))
 static const char* SYMS[] = {"—", "—", "(0.8)", "(203.5)", "***", "--", "&", "€", "·", "=="};
 #define N_SYMS (sizeof(SYMS) / sizeof(SYMS[0]))
 
@@ -106,7 +112,10 @@ static void prose_line(sink_t* s, rng_t* r, uint32_t width, int multibyte, uint3
         int cap = 0;
         if (*sentence_left == 0) { cap = 1; *sentence_left = 8 + below(r, 13); }
         if (below(r, 100) < 3) put_number(s, r, 6);
-        else if (multibyte && below(r, 10) == 0) { const char* w = MB_WORDS[below(r, N_MB)]; put(s, w, strlen(w)); }
+        else if (multibyte && below(r, 10) == 0) {
+            const char* w = (multibyte == 2 && below(r, 2)) ? WIDE_WORDS[below(r, N_WIDE)] : MB_WORDS[below(r, N_MB)];
+            put(s, w, strlen(w));
+        }
         else put_word(s, r, cap, 0);
         if (--*sentence_left == 0) putc1(s, '.');
     }
@@ -155,9 +164,9 @@ static void table_row(sink_t* s, rng_t* r) {
         putc1(s, '|');
     }
 }
-static void noisy_line(sink_t* s, rng_t* r, uint32_t* sentence_left) {
+static void noisy_line(sink_t* s, rng_t* r, uint32_t* sentence_left, int multibyte) {
     uint32_t k = below(r, 100);
-    if (k < 35) prose_line(s, r, 60 + below(r, 60), 1, sentence_left);
+    if (k < 35) prose_line(s, r, 60 + below(r, 60), multibyte, sentence_left);
     else if (k < 60) ocr_row(s, r);
     else if (k < 75) numeric_row(s, r);
     else if (k < 85) table_row(s, r);
@@ -173,8 +182,8 @@ static void gen_record(int kind, uint64_t seed, uint64_t r, uint64_t target, sin
     uint32_t sentence_left = 0;
     uint64_t next_blank = 500 + below(&g, 200);
     while (s->n - start + 140 < target) {
-        int noisy = kind == 1 || (kind == 2 && below(&g, 5) == 0);
-        if (noisy) noisy_line(s, &g, &sentence_left);
+        int noisy = kind == 1 || kind == 3 || (kind == 2 && below(&g, 5) == 0);
+        if (noisy) noisy_line(s, &g, &sentence_left, kind == 3 ? 2 : 1);
         else prose_line(s, &g, 80 + below(&g, 41), 0, &sentence_left);
         if (kind != 0 && below(&g, 20) == 0) put(s, "\r\n", 2);
         else putc1(s, '\n');

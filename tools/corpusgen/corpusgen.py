@@ -24,7 +24,7 @@ def lib():
     return _lib
 
 
-KINDS = {"B": 0, "C": 1, "D": 2}
+KINDS = {"B": 0, "C": 1, "D": 2, "W": 3}
 
 
 def generate(kind, seed, total_bytes, lo, hi, mode=0, threads=8, out=None):
@@ -52,3 +52,8 @@ def config_c(total_bytes=4_000_000_000, seed=43, threads=8):
 
 def config_d(total_bytes=1_000_000_000, seed=44, threads=8):
     return generate("D", seed, total_bytes, 200, 1 << 20, 1, threads)
+
+
+def config_w(total_bytes=1_000_000_000, seed=46, threads=8):
+    """Config C with half of its multi-byte words in scripts outside the classifier's bit-plane rules."""
+    return generate("W", seed, total_bytes, 2048, 16384, 0, threads)
