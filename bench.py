@@ -48,6 +48,37 @@ def path_algorithmic_bytes(s):
     return s["N"] + (s["D"] if s["enabled"] else 0) + 8 * s["T"] + 32 * s["C"] + 32 * (s["R"] + 1) + s["R"]
 
 
+def workload_name(config, nbytes):
+    if config == "B":
+        return "config B: %.1e B synthetic ASCII English, records 3072-5120 B" % nbytes
+    if config == "C":
+        return "config C: %.1e B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB" % nbytes
+    if config == "W":
+        return ("config C with wide scripts: %.1e B, half of the multibyte words Georgian / Ethiopic / Bengali / "
+                "Tamil / Armenian / Khmer / Tibetan / Cherokee (per-character classifier path)" % nbytes)
+    return "config D: %.1e B skewed lengths, half the bytes in 200 B and half in 1 MiB records" % nbytes
+
+
+def committed_traffic(workload, n_bytes, denoiser_enabled, kernel):
+    """HBM bytes per launch of `kernel` from the newest profiles/r*_traffic.json that was collected on exactly
+    this workload (same generator line, byte count and denoiser setting), or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+        except Exception:
+            continue
+        meta = tj.get("_meta", {})
+        if (meta.get("bytes_per_gpu") == n_bytes and meta.get("workload") == workload
+                and meta.get("denoiser") == ("enabled" if denoiser_enabled else "disabled")):
+            v = (tj.get(kernel) or {}).get("bytes")
+            if v is not None:
+                best = v   # file names sort by round
+    return best
+
+
 def kernel_profile(ctx, step, nb, reps):
     """Average duration of every kernel per launch (HIP events on the context's stream) over `reps` passes."""
     ctx.set_profiling(True)
@@ -140,11 +171,14 @@ def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup):
     ms = elapsed / steps * 1e3
     stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled}
     kern = kernel_profile(ctx, step, nb, 3)
+    roof = roofline_of(kern, stats, nb, ms)
+    if nb == 1:
+        roof["traffic"] = committed_traffic(workload, N, den.enabled, roof["kernel"])
     return {"workload": workload, "value": round(N * steps / elapsed / 1e9, 2), "unit": "GB/s",
             "ms_per_step": round(ms, 4), "steps": steps, "bytes": N, "records": R, "batches_per_step": nb,
             "overlap_tokens": list(st.overlap_tokens),
             "outputs": {"denoised_bytes": res[0], "tokens": res[1], "chunks": res[2]},
-            "roofline": roofline_of(kern, stats, nb, ms)}
+            "roofline": roof}
 
 
 def main():
@@ -214,19 +248,9 @@ def main():
     else:
         nbytes = args.bytes or 1_000_000_000
         seed = {"B": 42, "C": 43, "D": 44, "W": 46}[args.config] + 1000 * rank
-        if args.config == "B":
-            data, offs = corpusgen.config_b(nbytes, seed, threads)
-            workload = "config B: %.1e B synthetic ASCII English, records 3072-5120 B" % nbytes
-        elif args.config == "C":
-            data, offs = corpusgen.config_c(nbytes, seed, threads)
-            workload = "config C: %.1e B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB" % nbytes
-        elif args.config == "W":
-            data, offs = corpusgen.config_w(nbytes, seed, threads)
-            workload = ("config C with wide scripts: %.1e B, half of the multibyte words Georgian / Ethiopic / Bengali / "
-                        "Tamil / Armenian / Khmer / Tibetan / Cherokee (per-character classifier path)" % nbytes)
-        else:
-            data, offs = corpusgen.config_d(nbytes, seed, threads)
-            workload = "config D: %.1e B skewed lengths, half the bytes in 200 B and half in 1 MiB records" % nbytes
+        gen = {"B": corpusgen.config_b, "C": corpusgen.config_c, "D": corpusgen.config_d, "W": corpusgen.config_w}[args.config]
+        data, offs = gen(nbytes, seed, threads)
+        workload = workload_name(args.config, nbytes)
         batches.append((torch.from_numpy(data).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda(),
                         int(len(offs) - 1), int(len(data))))
         host0 = (data, offs)
@@ -323,18 +347,8 @@ def main():
     dominant = roofline["kernel"]
     # HBM bytes per launch of the dominant kernel from the committed counter runs (tools/collect_profiles.sh),
     # used only when they were taken on this very workload
-    tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr):
-        try:
-            with open(tr) as f:
-                tj = json.load(f)
-            meta = tj.get("_meta", {})
-            same = (nb == 1 and meta.get("bytes_per_gpu") == N and meta.get("workload") == workload
-                    and meta.get("denoiser") == ("enabled" if den.enabled else "disabled") and not args.normalize)
-            if same:
-                roofline["traffic"] = (tj.get(dominant) or {}).get("bytes")
-        except Exception:
-            pass
+    if nb == 1 and not args.normalize:
+        roofline["traffic"] = committed_traffic(workload, N, den.enabled, dominant)
 
     out = {
         "metric": "device-resident GB/s of text denoised+tokenised+chunked",
@@ -397,14 +411,13 @@ def main():
         dd, oo = corpusgen.config_c(4_000_000_000, 43, threads)
         bt = [to_dev(dd, oo)]
         del dd, oo
-        ex["C"] = run_extra(T, ctx, "C", "config C: 4.0e9 B synthetic OCR-noisy markdown, multibyte UTF-8, records 2-16 KB",
-                            bt, den, st, 5, 2)
+        ex["C"] = run_extra(T, ctx, "C", workload_name("C", 4_000_000_000), bt, den, st, 5, 2)
         del bt
         torch.cuda.empty_cache()
         dd, oo = corpusgen.config_d(1_000_000_000, 44, threads)
         bt = [to_dev(dd, oo)]
         del dd, oo
-        wl = "config D: 1.0e9 B skewed lengths, half the bytes in 200 B and half in 1 MiB records"
+        wl = workload_name("D", 1_000_000_000)
         ex["D"] = run_extra(T, ctx, "D", wl, bt, den, st, 5, 2)
         ex["D_overlaps_64_256"] = run_extra(T, ctx, "D", wl, bt, den, T.ChunkingStrategy(overlap_tokens=[64, 256]), 5, 2)
         del bt
@@ -412,9 +425,7 @@ def main():
         dd, oo = corpusgen.config_w(1_000_000_000, 46, threads)
         bt = [to_dev(dd, oo)]
         del dd, oo
-        ex["C_wide_scripts"] = run_extra(T, ctx, "W", "config C generator, 1.0e9 B, with half of the multibyte words in "
-                                         "scripts the classifier settles per character (Georgian, Ethiopic, Bengali, "
-                                         "Tamil, Armenian, Khmer, Tibetan, Cherokee)", bt, den, st, 5, 2)
+        ex["C_wide_scripts"] = run_extra(T, ctx, "W", workload_name("W", 1_000_000_000), bt, den, st, 5, 2)
         del bt
         torch.cuda.empty_cache()
         bt = []
