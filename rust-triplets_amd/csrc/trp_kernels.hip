@@ -2195,12 +2195,17 @@ struct trp_ctx {
     // Test aid: TRIPLETS_AMD_FORCE_SUMMARY=1 in the environment when the context is created makes every
     // batch take the per-tile-summary path for the tile seeds (normally only batches that k_seed cannot settle).
     u32 force_summary = 0;
+    // The summary kernels (k_summary, k_tile_carry_near, k_tile_carry) are launched only while batches need them:
+    // a batch whose tiles k_seed could not all settle is run again with them, and so are the batches after it
+    // until one comes along that k_seed settles alone.
+    bool summary_path = false;
     // batch in flight between submit_device and collect_device
     struct Pending {
         bool active = false;
         const uint8_t* d_bytes = nullptr;
         const uint64_t* d_offsets = nullptr;
         u64 R = 0, N = 0, nT = 0, g3_cap = 0, chunk_cap = 0;
+        bool with_summary = false;
         DevCfg dc = {};
     } pending;
     // Profiling aid: with profiling on and TRP_PROFILE_EMIT_STOP=k (1..5) in the environment, k_emit ends
@@ -2318,6 +2323,7 @@ static int create_ctx(int device, hipStream_t stream, bool own, trp_ctx** out) {
     trp_ctx* c = new trp_ctx();
     c->scratch_ptr = sp;
     { const char* e2 = getenv("TRIPLETS_AMD_FORCE_SUMMARY"); c->force_summary = (e2 && atoi(e2)) ? 1u : 0u; }
+    c->summary_path = c->force_summary != 0;
     c->device = device;
     c->owns_stream = own;
     c->stream = stream;
@@ -2427,7 +2433,7 @@ static u64 token_bound(u64 N, u64 R) { return (N + std::min<u64>(R, N)) / 2 + 4;
 // Enqueues the kernels of the whole path for one batch on `st`; nothing is allocated here.  `c` supplies the
 // profiling switches only.
 static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uint8_t* d_bytes, const uint64_t* d_offsets,
-                        uint64_t R, uint64_t N, const DevCfg& dc) {
+                        uint64_t R, uint64_t N, const DevCfg& dc, bool with_summary) {
     int rc;
     const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
     const bool pass = !dc.denoise_enabled;
@@ -2456,7 +2462,10 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
               else
                   hipLaunchKernelGGL(k_seed<false>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, c->force_summary,
                                      B.seedJ, B.seedS, open_count); }
-            // the next three return at once unless k_seed left tiles open
+            // the tile seeds again from per-tile summaries, for the tiles k_seed left open (the three kernels return
+            // at once when there are none; they are not even launched while batches do not need them: totals[8]
+            // tells the host, which then runs the batch again)
+            if (with_summary) {
             { Prof pr(c, "k_summary");
               const dim3 grid((unsigned)std::min<u64>(nT, SUMMARY_GRID));
               if (dc.normalize) hipLaunchKernelGGL(k_summary<true>, grid, dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, nT, open_count, SA);
@@ -2467,6 +2476,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                  open_count, B.seedJ, B.seedS, B.far_list, far_count);
               hipLaunchKernelGGL(k_tile_carry, dim3((unsigned)std::min<u64>((nT + NT / 64 - 1) / (NT / 64), 1024)), dim3(NT), 0, st,
                                  SA, nT, B.seedJ, B.seedS, B.far_list, far_count); }
+            }
             { Prof pr(c, "k_plan");
               if (dc.normalize)
                   hipLaunchKernelGGL(k_plan<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
@@ -2583,8 +2593,9 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     B.tok_start = c->tok_start.as<u32>(); B.tok_len = c->tok_len.as<u32>();
     B.chunks = c->chunks.as<ChunkDesc>(); B.chunk_cap = chunk_cap;
     drop_events(c);
-    if ((rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc))) return rc;
-    HIPCHK(hipMemcpyAsync(c->h_totals, B.totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    const bool with_summary = c->summary_path;
+    if ((rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc, with_summary))) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_totals, B.totals, 9 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     c->pending.active = true;
     c->pending.d_bytes = d_bytes;
     c->pending.d_offsets = d_offsets;
@@ -2593,6 +2604,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     c->pending.nT = nT;
     c->pending.g3_cap = g3_cap;
     c->pending.chunk_cap = chunk_cap;
+    c->pending.with_summary = with_summary;
     c->pending.dc = dc;
     return TRP_OK;
 }
@@ -2612,6 +2624,16 @@ static int collect_device(trp_ctx* c, trp_result* out) {
     u64* totals = c->totals.as<u64>();
     u64 *den_off = c->den_off.as<u64>(), *tok_off = c->tok_off.as<u64>(), *chunk_off = c->chunk_off.as<u64>();
     HIPCHK(hipStreamSynchronize(st));
+    if (!pass && nT) {
+        const bool open = (u32)c->h_totals[8] != 0;   // k_seed left tiles open (or the test switch forces the path)
+        if (open && !pd.with_summary) {
+            // the tile seeds of this batch are incomplete: run it again with the summary kernels
+            c->summary_path = true;
+            if ((rc = submit_device(c, pd.d_bytes, pd.d_offsets, pd.R, pd.N, dc))) return rc;
+            return collect_device(c, out);
+        }
+        if (!open && !c->force_summary) c->summary_path = false;
+    }
     if (!pass && nT && c->h_totals[5]) {
         // more digit-heavy lines than the work list holds: grow it to the exact size and run the batch again
         if (c->h_totals[4] <= pd.g3_cap) return fail(TRP_E_HIP, "inconsistent gate-3 list size");
@@ -2715,11 +2737,20 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
     // per-kernel event pairs would have to be created: this entry point is never profiled
     const bool was_profiling = c->profiling;
     c->profiling = false;
-    rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc);   // starts by clearing the totals and counters
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool with_summary = c->summary_path;
+        rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc, with_summary);   // starts by clearing the totals and counters
+        if (rc) break;
+        hipError_t e = hipMemcpyAsync(c->h_totals, B.totals, 9 * sizeof(u64), hipMemcpyDeviceToHost, c->stream);   // into pinned memory
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(TRP_E_HIP, std::string("noalloc batch: ") + hipGetErrorString(e)); break; }
+        const bool open = !pass && N && (u32)c->h_totals[8] != 0;
+        if (open && !with_summary) { c->summary_path = true; continue; }   // once more, with the summary kernels
+        if (!pass && N && !open && !c->force_summary) c->summary_path = false;
+        break;
+    }
     c->profiling = was_profiling;
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->h_totals, B.totals, 6 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));   // into pinned memory
-    HIPCHK(hipStreamSynchronize(c->stream));
     memset(out, 0, sizeof(*out));
     out->n_records = R;
     out->n_denoised = c->h_totals[0];
