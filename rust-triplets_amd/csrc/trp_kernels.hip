@@ -16,9 +16,9 @@
 //
 // Kernel sequence with the denoiser enabled:
 //   k_rec_lo -> k_seed (-> k_summary -> k_tile_carry when k_seed left tiles open) -> k_plan -> k_gate3_solve
-//   -> k_pack_tiles -> scan(3) -> k_emit
-//   -> k_finish_count -> scan(3) -> k_chunk_emit
-// and with it disabled: k_rec_lo -> k_count_tokens -> k_pack_tiles -> scan(3) -> k_emit<passthrough> ...
+//   -> scan of the sub-tile counts (2) -> k_emit
+//   -> scan of the chunk counts (2; totals, trailing offsets and dropped flags on the way) -> k_chunk_emit
+// and with it disabled: k_rec_lo -> k_count_tokens -> scan(2) -> k_emit<passthrough> ...
 //
 // The per-lane logic lives in trp_lane.h (shared with the host simulator).
 #include <hip/hip_runtime.h>
@@ -540,9 +540,11 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
 // rec_lo[nT+1] = number of records whose start offset is < N.
 // ---------------------------------------------------------------------------------------------------
 // rec_lo_w: the same for sub-tiles (w = 0..nW, and rec_lo_w[nW+1] for N).
+// The first kernel of a batch: it also clears the batch's totals and counters (totals[0..15]).
 __global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW, u32* __restrict__ rec_lo,
-                         u32* __restrict__ rec_lo_w) {
+                         u32* __restrict__ rec_lo_w, u64* __restrict__ totals) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16) totals[i] = 0;
     u64 key;
     u32* dst;
     if (i <= nT + 1) { key = i <= nT ? i * (u64)TILE : N; dst = rec_lo + i; }
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     sh.tokc[tid] = TOKC;
     __syncthreads();
     // The counts are kept per sub-tile (= per wavefront).  A token that runs into a sub-tile from the left is
-    // counted as a start by the sub-tile (k_pack_tiles takes it back, from the flags).
+    // counted as a start by the sub-tile (GenTiles takes it back, from the flags).
     bool prev_tok = lane > 0 && (sh.tokc[tid - 1] >> 63);
     u64 TS = token_starts(TOKC, L.d.RS, prev_tok);
     u32 nb = popc(pl.C) + popc(PFX), ntk = popc(TS), nmk = popc(marks);
@@ -1402,16 +1404,116 @@ __global__ __launch_bounds__(NT) void k_scan_final(const u64* __restrict__ in, u
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
 }
 
-// tile counts -> packed u64 (bytes | toks << 32); a token that continues across a tile edge was
-// counted as a start by the right-hand tile: take it back here.
+// The two scans of the path in two kernels each.  k_scan_reduce_gen computes the values to be scanned with a
+// generator (which also stores them for the second kernel) and reduces them per workgroup; k_scan_final_sum
+// adds up the partial sums before its own workgroup itself instead of waiting for a single-workgroup scan of
+// them in between (a few loads per thread: there are n / 2048 partial sums; beyond SCAN_SUM_MAX of them the
+// three-kernel form is used).  Letting the last workgroup of the first kernel scan the partial sums instead was
+// measured slower: the device-wide fence it needs writes back every workgroup's L2 lines.
+//
+// GenTiles: sub-tile counts -> packed u64 (bytes | toks << 32); a token that continues across a sub-tile edge
+// was counted as a start by the right-hand sub-tile: taken back here.
+struct GenTiles {
+    const u32 *bytes, *toks, *flags;
+    u64* packed;
+    __device__ u64 operator()(u64 t) const {
+        u32 tk = toks[t];
+        if (t > 0 && (flags[t] & TF_FIRST_CONT) && (flags[t - 1] & TF_LAST_TOK)) tk -= 1;
+        const u64 v = (u64)bytes[t] | ((u64)tk << 32);
+        packed[t] = v;
+        return v;
+    }
+    struct State {};
+    __device__ State begin() const { return State(); }
+    __device__ u64 at(const State&, u64 t) const { return (*this)(t); }
+    __device__ void once() const {}
+};
+// GenChunkCounts: per record the number of chunks; on the way the totals, the offsets of records that start at
+// the very end of the corpus (k_emit only sees records that start inside a sub-tile) and the dropped flags.
+struct GenChunkCounts {
+    const u64* tile_base;
+    u64 nW;
+    const u32* rec_lo_w;
+    u64 R, N;
+    int passthrough;
+    DevCfg cfg;
+    u64 *den_off, *tok_off, *totals, *counts;
+    u8* dropped;
+    struct State { u64 D, T, first; };
+    __device__ State begin() const {
+        State e;
+        e.D = nW ? (tile_base[nW] & 0xFFFFFFFFull) : 0;
+        e.T = nW ? (tile_base[nW] >> 32) : 0;
+        if (passthrough) e.D = N;
+        e.first = rec_lo_w[nW + 1];   // first record whose start offset is >= N
+        return e;
+    }
+    __device__ u64 at(const State& e, u64 r) const {
+        const u64 D = e.D, T = e.T, first = e.first;
+        // entries at and after `first` are written here, by their own thread: neighbours never read them
+        const u64 d0 = r >= first ? D : den_off[r], t0 = r >= first ? T : tok_off[r];
+        const u64 d1 = r + 1 >= first ? D : den_off[r + 1], t1 = r + 1 >= first ? T : tok_off[r + 1];
+        if (r >= first) { den_off[r] = D; tok_off[r] = T; }
+        const u64 n = chunk_count(t1 - t0, cfg);
+        counts[r] = n;
+        dropped[r] = cfg.denoise_enabled && !cfg.normalize && d1 == d0;
+        return n;
+    }
+    __device__ void once() const {
+        const State e = begin();
+        totals[0] = e.D;
+        totals[1] = e.T;
+        den_off[R] = e.D;
+        tok_off[R] = e.T;
+    }
+};
 
-__global__ void k_pack_tiles(const u32* __restrict__ tile_bytes, const u32* __restrict__ tile_toks,
-                             const u32* __restrict__ tile_flags, u64 nT, u64* __restrict__ packed) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nT) return;
-    u32 tk = tile_toks[t];
-    if (t > 0 && (tile_flags[t] & TF_FIRST_CONT) && (tile_flags[t - 1] & TF_LAST_TOK)) tk -= 1;
-    packed[t] = (u64)tile_bytes[t] | ((u64)tk << 32);
+constexpr u64 SCAN_SUM_MAX = 8192;
+template <class Gen>
+__global__ __launch_bounds__(NT) void k_scan_reduce_gen(Gen gen, u64 n, u64* __restrict__ partial) {
+    __shared__ u64 red[NT / 64];
+    // consecutive threads take consecutive elements (the order within the workgroup's chunk does not matter here)
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x;
+    const typename Gen::State st = gen.begin();
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + (u64)i * NT < n) s += gen.at(st, base + (u64)i * NT);
+    if (blockIdx.x == 0 && threadIdx.x == 0) gen.once();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 tot = 0;
+        for (int w = 0; w < NT / 64; w++) tot += red[w];
+        partial[blockIdx.x] = tot;
+    }
+}
+// k_scan_final with the workgroup's base summed from the (unscanned) partial sums of the workgroups before it
+__global__ __launch_bounds__(NT) void k_scan_final_sum(const u64* __restrict__ in, u64 n, const u64* __restrict__ partial,
+                                                        u64* __restrict__ out) {
+    __shared__ u64 smem[NT / 64];
+    __shared__ u64 bsum[NT / 64];
+    u64 pre = 0;
+    for (u64 i = threadIdx.x; i < blockIdx.x; i += NT) pre += partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_down(pre, off, 64);
+    if ((threadIdx.x & 63) == 0) bsum[threadIdx.x >> 6] = pre;
+    u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x * SCAN_ITEMS;
+    u64 v[SCAN_ITEMS];
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    u64 tot;
+    u64 ex = block_excl_sum_u64(s, smem, &tot);   // barriers inside: bsum is complete afterwards
+    for (int w = 0; w < NT / 64; w++) ex += bsum[w];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+        if (base + i + 1 == n) out[n] = ex;
+    }
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1871,34 +1973,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     }
 }
 
-// Totals, the offsets of records that start at the very end of the corpus (k_emit only sees records that
-// start inside a tile), and per record: the number of chunks and the dropped flag.  One thread per entry
-// of the offset arrays (R + 1).
-__global__ void k_finish_count(const u64* __restrict__ tile_base, u64 nW, const u32* __restrict__ rec_lo_w, u64 R,
-                               u64 N, int passthrough, DevCfg cfg, u64* __restrict__ den_off,
-                               u64* __restrict__ tok_off, u64* __restrict__ totals, u64* __restrict__ counts,
-                               u8* __restrict__ dropped) {
-    u64 D = nW ? (tile_base[nW] & 0xFFFFFFFFull) : 0, T = nW ? (tile_base[nW] >> 32) : 0;
-    if (passthrough) D = N;
-    const u64 first = rec_lo_w[nW + 1];   // first record whose start offset is >= N
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0) { totals[0] = D; totals[1] = T; }
-    if (r > R) return;
-    if (r >= first) { den_off[r] = D; tok_off[r] = T; }
-    if (r == R) return;
-    const u64 d0 = r >= first ? D : den_off[r], t0 = r >= first ? T : tok_off[r];
-    const u64 d1 = r + 1 >= first ? D : den_off[r + 1], t1 = r + 1 >= first ? T : tok_off[r + 1];
-    counts[r] = chunk_count(t1 - t0, cfg);
-    dropped[r] = cfg.denoise_enabled && !cfg.normalize && d1 == d0;
-}
-
 // One lane per record (wavefronts stride over the records): a record's first CHUNK_INLINE descriptors are
 // written by its lane, the rest of a record with many windows by the whole wavefront.
 constexpr u32 CHUNK_INLINE = 4;
+// The last kernel of a batch: its first thread also copies the batch's totals and flags (totals[0..8]) into the
+// page-locked host words `host_totals`, which spares a copy command behind the kernels.
 __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off, u64 R, DevCfg cfg,
-                             u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals) {
+                             u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals,
+                             u64* __restrict__ host_totals) {
     const u64 C = chunk_off[R];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[2] = C; totals[3] = C > capacity ? 1 : 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        totals[2] = C;
+        totals[3] = C > capacity ? 1 : 0;
+        if (host_totals) {
+            for (int i = 0; i < 9; i++) host_totals[i] = i == 2 ? C : i == 3 ? (u64)(C > capacity ? 1 : 0) : totals[i];
+            __threadfence_system();
+        }
+    }
     if (C > capacity) return;
     const int lane = threadIdx.x & 63;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -2280,6 +2371,21 @@ int scan_u64_with(hipStream_t st, u64* partial, const u64* in, u64 n, u64* out) 
     HIPCHK(hipGetLastError());
     return TRP_OK;
 }
+// The path's own scans: values from a generator, two kernels (see k_scan_reduce_gen).  `values` is where the
+// generator stores what it computes.
+template <class Gen>
+int scan_gen(hipStream_t st, u64* partial, const Gen& gen, const u64* values, u64 n, u64* out) {
+    const u64 nb = scan_partials(n);
+    hipLaunchKernelGGL(k_scan_reduce_gen<Gen>, dim3((unsigned)nb), dim3(NT), 0, st, gen, n, partial);
+    if (nb <= SCAN_SUM_MAX) {
+        hipLaunchKernelGGL(k_scan_final_sum, dim3((unsigned)nb), dim3(NT), 0, st, values, n, partial, out);
+    } else {
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, st, partial, nb);
+        hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(NT), 0, st, values, n, partial, out);
+    }
+    HIPCHK(hipGetLastError());
+    return TRP_OK;
+}
 int scan_u64(trp_ctx* c, const u64* in, u64 n, u64* out) {
     int rc = c->partial.ensure(scan_partials(n) * sizeof(u64));
     if (rc) return rc;
@@ -2444,12 +2550,10 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
     u64* totals = B.totals;
     const PlanMem plan = plan_view(B.plan, nB);
     J* SA = B.SA;
-    HIPCHK(hipMemsetAsync(totals, 0, 16 * sizeof(u64), st));
-
     {
-        Prof pr(c, "k_rec_lo");
+        Prof pr(c, "k_rec_lo");   // also clears the totals and counters
         hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + nW + 4 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, nW, rec_lo,
-                           B.rec_lo_w);
+                           B.rec_lo_w, totals);
     }
     if (nT) {
         if (!pass) {
@@ -2495,9 +2599,8 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                tflags);
         }
         { Prof pr(c, "scan_tiles");
-          hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, st, tbytes, ttoks, tflags, nW,
-                             B.packed);
-          if ((rc = scan_u64_with(st, B.partial, B.packed, nW, tile_base))) return rc; }
+          const GenTiles gen = {tbytes, ttoks, tflags, B.packed};
+          if ((rc = scan_gen(st, B.partial, gen, B.packed, nW, tile_base))) return rc; }
         { Prof pr(c, "k_emit");
           if (pass)
               hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
@@ -2508,14 +2611,15 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                  d_offsets, B.rec_lo_w, R, N, nB, nW, plan, tile_base, B.denoised, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop()); }
     }
-    { Prof pr(c, "k_finish_count");
-      hipLaunchKernelGGL(k_finish_count, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, tile_base, nW, B.rec_lo_w, R, N,
-                         pass ? 1 : 0, dc, den_off, tok_off, totals, B.counts, B.dropped); }
-    { Prof pr(c, "scan_chunks");
-      if ((rc = scan_u64_with(st, B.partial, B.counts, R, chunk_off))) return rc; }
+    { Prof pr(c, "scan_chunks");   // with the totals, the trailing offsets and the dropped flags on the way
+      GenChunkCounts gen;
+      gen.tile_base = tile_base; gen.nW = nW; gen.rec_lo_w = B.rec_lo_w; gen.R = R; gen.N = N;
+      gen.passthrough = pass ? 1 : 0; gen.cfg = dc;
+      gen.den_off = den_off; gen.tok_off = tok_off; gen.totals = totals; gen.counts = B.counts; gen.dropped = B.dropped;
+      if ((rc = scan_gen(st, B.partial, gen, B.counts, R, chunk_off))) return rc; }
     { Prof pr(c, "k_chunk_emit");
       hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, B.chunk_cap,
-                         B.chunks, totals); }
+                         B.chunks, totals, c->h_totals); }   // the totals reach the host with this kernel
     HIPCHK(hipGetLastError());
     return TRP_OK;
 }
@@ -2595,7 +2699,6 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     drop_events(c);
     const bool with_summary = c->summary_path;
     if ((rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc, with_summary))) return rc;
-    HIPCHK(hipMemcpyAsync(c->h_totals, B.totals, 9 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     c->pending.active = true;
     c->pending.d_bytes = d_bytes;
     c->pending.d_offsets = d_offsets;
@@ -2646,8 +2749,7 @@ static int collect_device(trp_ctx* c, trp_result* out) {
         const u64 chunk_cap = c->h_totals[2];
         if ((rc = c->chunks.ensure(chunk_cap * sizeof(ChunkDesc)))) return rc;
         hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, chunk_cap,
-                           c->chunks.as<ChunkDesc>(), totals);
-        HIPCHK(hipMemcpyAsync(c->h_totals, totals, 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+                           c->chunks.as<ChunkDesc>(), totals, c->h_totals);
         HIPCHK(hipStreamSynchronize(st));
         if (c->h_totals[3]) return fail(TRP_E_HIP, "chunk descriptor buffer overflow");
     }
@@ -2741,8 +2843,7 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
         const bool with_summary = c->summary_path;
         rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc, with_summary);   // starts by clearing the totals and counters
         if (rc) break;
-        hipError_t e = hipMemcpyAsync(c->h_totals, B.totals, 9 * sizeof(u64), hipMemcpyDeviceToHost, c->stream);   // into pinned memory
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipStreamSynchronize(c->stream);   // the last kernel has written the totals into pinned memory
         if (e != hipSuccess) { rc = fail(TRP_E_HIP, std::string("noalloc batch: ") + hipGetErrorString(e)); break; }
         const bool open = !pass && N && (u32)c->h_totals[8] != 0;
         if (open && !with_summary) { c->summary_path = true; continue; }   // once more, with the summary kernels
