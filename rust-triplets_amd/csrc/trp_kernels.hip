@@ -45,11 +45,12 @@ using namespace trp;
 namespace {
 
 constexpr int NT = TILE_BLOCKS;   // threads per workgroup
-// k_emit works on sub-tiles: the 64 blocks (4 KiB) of one wavefront of a tile.  The emitted byte / token counts
-// and their scanned bases are kept per sub-tile.
-constexpr int SUB_BLOCKS = 64;
+// k_emit works on sub-tiles of 32 blocks (2 KiB): one wavefront per sub-tile, one lane per half block (32 bytes,
+// 32-bit masks), which keeps a wave's LDS and registers small enough for eight waves per SIMD.  The emitted
+// byte / token counts and their scanned bases are kept per sub-tile (= per half wavefront of k_plan).
+constexpr int SUB_BLOCKS = 32;
 constexpr int SUB = SUB_BLOCKS * BLOCK;
-constexpr int SUBS_PER_TILE = TILE_BLOCKS / SUB_BLOCKS;
+constexpr int HALF = 32;   // bytes per lane of k_emit
 
 __device__ inline UniTables dev_tables() {
     UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
@@ -410,8 +411,6 @@ __device__ inline void tile_store(const TileRegs& r, u8* sb) {
     if (tid == 0) lds_store16(sb + 48, r.halo);                                  // last 16 bytes of block -1
     else if (tid == 1) lds_store16(sb + (TILE_BLOCKS + 1) * PAD_STRIDE, r.halo);
 }
-struct SubShared;
-__device__ inline PadBlk lane_block_sub(const SubShared& sh, int i);
 __device__ inline PadBlk lane_block(const TileShared& sh, int i) {
     PadBlk b = {sh.bytes + (i + 1) * PAD_STRIDE};
     return b;
@@ -1117,21 +1116,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
     sh.tokc[tid] = TOKC;
     __syncthreads();
-    // The counts are kept per sub-tile (= per wavefront).  A token that runs into a sub-tile from the left is
-    // counted as a start by the sub-tile (GenTiles takes it back, from the flags).
-    bool prev_tok = lane > 0 && (sh.tokc[tid - 1] >> 63);
+    // The counts are kept per sub-tile (= per half wavefront: 32 blocks).  A token that runs into a sub-tile from
+    // the left is counted as a start by the sub-tile (GenTiles takes it back, from the flags).
+    bool prev_tok = (lane & (SUB_BLOCKS - 1)) > 0 && (sh.tokc[tid - 1] >> 63);
     u64 TS = token_starts(TOKC, L.d.RS, prev_tok);
     u32 nb = popc(pl.C) + popc(PFX), ntk = popc(TS), nmk = popc(marks);
-    const bool last_tok = __shfl((int)(u32)(TOKC >> 63), 63, 64) != 0;
+    const bool last_tok = __shfl((int)(u32)(TOKC >> 63), lane | (SUB_BLOCKS - 1), 64) != 0;   // last lane of the half
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        nb += __shfl_down((int)nb, off, 64);
-        ntk += __shfl_down((int)ntk, off, 64);
-        nmk += __shfl_down((int)nmk, off, 64);
+    for (int off = SUB_BLOCKS / 2; off > 0; off >>= 1) {   // sums over the lanes of each half, in lanes 0 and 32
+        nb += __shfl_down((int)nb, off, SUB_BLOCKS);
+        ntk += __shfl_down((int)ntk, off, SUB_BLOCKS);
+        nmk += __shfl_down((int)nmk, off, SUB_BLOCKS);
     }
-    if (lane == 0) {
-        sh.red[2][wave] = nmk;
-        const u64 sub = t * (u64)SUBS_PER_TILE + (u64)wave;
+    const u32 nmk_hi = (u32)__shfl((int)nmk, SUB_BLOCKS, 64);
+    if (lane == 0) sh.red[2][wave] = nmk + nmk_hi;
+    if ((lane & (SUB_BLOCKS - 1)) == 0) {
+        const u64 sub = b / SUB_BLOCKS;
         if (sub * (u64)SUB < N) {
             tile_bytes[sub] = nb;
             tile_toks[sub] = ntk;
@@ -1158,13 +1158,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
 
 __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                                       const u32* __restrict__ rec_lo, u64 R, u64 N,
-                                                      u64 nB, u32* __restrict__ tile_bytes,
+                                                      u64 nB, PlanMem plan, u32* __restrict__ tile_bytes,
                                                       u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
     __shared__ TileShared sh;
     __shared__ UniShared uni;
     __shared__ u64 tokc[TILE_BLOCKS];
     __shared__ RsShared rs;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
     {
         TileRegs regs;
@@ -1178,15 +1178,17 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
     __syncthreads();
     LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs.w[tid], rs.w[tid + 1]);
     Plan pl = plan_passthrough(L.c, L.d.V);
+    // the copy and token planes go to the plan, so that k_emit need not classify the bytes again
+    if (L.nvalid > 0) { const PlanCT ct = {pl.C, pl.TOK}; plan.ct[t * (u64)TILE_BLOCKS + tid] = ct; }
     tokc[tid] = pl.TOK;
     __syncthreads();
-    bool prev_tok = lane > 0 && (tokc[tid - 1] >> 63);   // counts per sub-tile, as in k_plan
+    bool prev_tok = (lane & (SUB_BLOCKS - 1)) > 0 && (tokc[tid - 1] >> 63);   // counts per sub-tile, as in k_plan
     u32 ntk = popc(token_starts(pl.TOK, L.d.RS, prev_tok));
-    const bool last_tok = __shfl((int)(u32)(pl.TOK >> 63), 63, 64) != 0;
+    const bool last_tok = __shfl((int)(u32)(pl.TOK >> 63), lane | (SUB_BLOCKS - 1), 64) != 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ntk += __shfl_down((int)ntk, off, 64);
-    if (lane == 0) {
-        const u64 sub = t * (u64)SUBS_PER_TILE + (u64)wave, sS = sub * (u64)SUB;
+    for (int off = SUB_BLOCKS / 2; off > 0; off >>= 1) ntk += __shfl_down((int)ntk, off, SUB_BLOCKS);
+    if ((lane & (SUB_BLOCKS - 1)) == 0) {
+        const u64 sub = (t * (u64)TILE_BLOCKS + tid) / SUB_BLOCKS, sS = sub * (u64)SUB;
         if (sS < N) {
             tile_bytes[sub] = (u32)(N - sS < (u64)SUB ? N - sS : (u64)SUB);
             tile_toks[sub] = ntk;
@@ -1524,43 +1526,38 @@ __global__ __launch_bounds__(NT) void k_scan_final_sum(const u64* __restrict__ i
 struct __attribute__((packed, aligned(4))) Quad32 { u32 x, y, z, w; };
 struct Pair32 { u32 lo, hi; };   // two consecutive dwords at a 4-byte aligned address
 
-// ---- sub-tile staging (one wavefront, 64 blocks) ------------------------------------------------------
-// Same LDS layout as TileShared: block i of the sub-tile lives at (i + 1) * PAD_STRIDE.
+// ---- sub-tile staging (one wavefront, 64 half blocks of 32 bytes) -------------------------------------
+// LDS image of a sub-tile: the 32 bytes of lane l live at l * HALF_STRIDE (32 data bytes + 4 unused, so that
+// lanes that touch the same dword of their half blocks fall into different banks: 9 dwords per lane).  One
+// spare slot at the end: the aligned reads of a run copy may touch the dword after a half block.
+constexpr int HALF_STRIDE = 36;
 struct SubShared {
-    alignas(16) u8 bytes[(SUB_BLOCKS + 2) * PAD_STRIDE];
+    alignas(16) u8 bytes[(64 + 1) * HALF_STRIDE];
 };
 struct SubRs {
-    u64 w[SUB_BLOCKS + 1];
+    u32 w[64 + 1];   // record starts, one bit per byte: w[l] covers lane l; bit 0 of w[64]: the byte after the sub-tile
 };
 struct SubRegs {
     uint4 v[SUB / 16 / 64];
-    uint4 halo;   // lane 0: the 16 bytes before the sub-tile; lane 1: the 16 bytes after it
 };
 __device__ inline void sub_load(const u8* __restrict__ g, u64 N, u64 sS, SubRegs& r) {
     const int lane = threadIdx.x;
-    if (sS >= HALO && sS + SUB + HALO <= N) {
+    if (sS + SUB <= N) {
         const uint4* src = reinterpret_cast<const uint4*>(g + sS);
 #pragma unroll
         for (int k = 0; k < SUB / 16 / 64; k++) r.v[k] = src[k * 64 + lane];
-        r.halo = make_uint4(0, 0, 0, 0);
-        if (lane < 2) r.halo = *reinterpret_cast<const uint4*>(g + (lane == 0 ? sS - HALO : sS + SUB));
         return;
     }
 #pragma unroll
     for (int k = 0; k < SUB / 16 / 64; k++) r.v[k] = load16_guarded(g, N, sS + (u64)(k * 64 + lane) * 16);
-    r.halo = make_uint4(0, 0, 0, 0);
-    if (lane == 0) { if (sS >= HALO) r.halo = load16_guarded(g, N, sS - HALO); }
-    else if (lane == 1) r.halo = load16_guarded(g, N, sS + SUB);
 }
 __device__ inline void sub_store(const SubRegs& r, u8* sb) {
     const int lane = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < SUB / 16 / 64; k++) {
-        const int c = k * 64 + lane;
-        lds_store16(sb + ((c >> 2) + 1) * PAD_STRIDE + (c & 3) * 16, r.v[k]);
+        const int c = k * 64 + lane;   // 16-byte chunk c: half block c / 2, its first or second 16 bytes
+        lds_store16(sb + (c >> 1) * HALF_STRIDE + (c & 1) * 16, r.v[k]);
     }
-    if (lane == 0) lds_store16(sb + 48, r.halo);
-    else if (lane == 1) lds_store16(sb + (SUB_BLOCKS + 1) * PAD_STRIDE, r.halo);
 }
 // Record starts of sub-tile s: records [rec_lo_w[s], rec_lo_w[s+1]) start inside it (see rs_fetch / rs_store).
 __device__ inline u32 sub_rs_fetch(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 s,
@@ -1574,12 +1571,12 @@ __device__ inline u32 sub_rs_fetch(const u64* __restrict__ offsets, const u32* _
 }
 __device__ inline void sub_rs_set(SubRs& rs, u64 q, u64 N, u64 sS) {
     const u64 d = q - sS;
-    if (q < N && d <= (u64)SUB) atomicOr(reinterpret_cast<unsigned long long*>(&rs.w[d >> 6]), 1ull << (d & 63));
+    if (q < N && d <= (u64)SUB) atomicOr(&rs.w[d >> 5], 1u << (d & 31));
 }
 __device__ inline void sub_rs_store(const RsFetch& f, const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w,
                                     u64 R, u64 N, u64 s, SubRs& rs) {
     const u64 sS = s * (u64)SUB;
-    for (int i = threadIdx.x; i <= SUB_BLOCKS; i += 64) rs.w[i] = 0;
+    for (int i = threadIdx.x; i <= 64; i += 64) rs.w[i] = 0;
     if (f.q != ~0u) sub_rs_set(rs, f.q, N, sS);
     if (f.n >= 64) {   // crowded sub-tile: the rest of its records
         const u64 r0 = rec_lo_w[s], r1 = (u64)r0 + f.n;
@@ -1587,13 +1584,8 @@ __device__ inline void sub_rs_store(const RsFetch& f, const u64* __restrict__ of
     }
 }
 
-__device__ inline PadBlk lane_block_sub(const SubShared& sh, int i) {
-    PadBlk b = {sh.bytes + (i + 1) * PAD_STRIDE};
-    return b;
-}
-
-// Once the run copies are done the input image is dead; its space then holds the staged token table: 17 tokens
-// per block on average (English text has 11); the tokens of a denser sub-tile beyond that are stored directly.
+// Once the run copies are done the input image is dead; its space then holds the staged token table: 18 tokens
+// per 64 bytes on average (English text has 11); the tokens of a denser sub-tile beyond that are stored directly.
 constexpr u32 TOK_CAP = sizeof(SubShared) / sizeof(u32);
 
 struct EmitShared {
@@ -1605,74 +1597,54 @@ struct EmitShared {
 };
 static_assert(sizeof(SubRs) <= SUB + 64, "record-start words must fit in the output image");
 
-// Position where the token covering byte tS-1 starts (the tile's first byte continues it).
-template <bool PASSTHROUGH>
-__device__ inline u64 find_token_start_before(const u8* __restrict__ bytes, u64 N, const PlanCT* __restrict__ plan,
-                                              u64 tS, u64 rec_start) {
-    if (PASSTHROUGH) {
-        u64 q = tS;   // bytes [q, tS) are token bytes
-        while (q > rec_start) {
-            u8 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            u64 c = q - 1;
-            for (int i = -3; i <= 3; i++) {
-                long long a = (long long)c + i;
-                w[i + 3] = (a >= 0 && (u64)a < N) ? bytes[a] : 0;
-            }
-            PlainBlk wb = {w};
-            if (byte_is_ws(wb, 3)) break;
-            q--;
-        }
-        return q;
-    } else {
-        u64 bb = tS / 64;
-        while (bb > 0) {
-            bb--;
-            u64 w = plan[bb].TOK & plan[bb].C;
-            u64 lo = bb * 64;
-            u64 allow = rec_start > lo ? ~below((int)(rec_start - lo)) : ~0ull;   // bits at/after the record start
-            u64 zero = ~w & allow;
-            if (zero) return lo + top(zero) + 1;
-            if (rec_start >= lo) return rec_start;
-        }
-        return rec_start;
+// Position where the token covering byte tS-1 starts (the sub-tile's first byte continues it): a walk back over
+// the token planes of the blocks before, at most to the start of the record.
+__device__ inline u64 find_token_start_before(const PlanCT* __restrict__ plan, u64 tS, u64 rec_start) {
+    u64 bb = tS / 64;
+    while (bb > 0) {
+        bb--;
+        u64 w = plan[bb].TOK & plan[bb].C;
+        u64 lo = bb * 64;
+        u64 allow = rec_start > lo ? ~below((int)(rec_start - lo)) : ~0ull;   // bits at/after the record start
+        u64 zero = ~w & allow;
+        if (zero) return lo + top(zero) + 1;
+        if (rec_start >= lo) return rec_start;
     }
+    return rec_start;
 }
 
-// What a wavefront fetches from global memory for one sub-tile; fetched for sub-tile s+1 while s is processed.
+// What a wavefront fetches from global memory for its sub-tile.  Lane l owns half h = l & 1 of block
+// 32 s + (l >> 1): the 32 bits of the block's plan words that cover its bytes.
 struct EmitIn {
     SubRegs regs;
-    Plan pl;
+    PlanCT ct;            // the block's copy and token planes (both halves)
     RsFetch rf;           // record starts inside the sub-tile
     u32 rec0;             // first record that starts inside the sub-tile
     u64 prev_w;           // lane 0: token bytes of the block before the sub-tile
     u32 prev_rec;         // lane 0: start of the last record before the sub-tile
     u64 next_w;           // last lane: token bytes of the block after the sub-tile
     u64 base;             // scanned output byte / token base of the sub-tile
-    u64 pfx;              // blocks of the sub-tile whose separator planes are stored
+    u32 pfx;              // blocks of the sub-tile whose separator planes are stored (bit i: block 32 s + i)
 };
-template <bool PASSTHROUGH>
 __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                   const u32* __restrict__ rec_lo_w, u64 R, const PlanMem& plan,
-                                  const u64* __restrict__ tile_base, u64 N, u64 nB, u64 s, EmitIn& in) {
+                                  const u64* __restrict__ tile_base, u64 N, u64 nB, u64 s, bool passthrough, EmitIn& in) {
     const int lane = threadIdx.x;
-    const u64 b = s * (u64)SUB_BLOCKS + lane;
-    sub_load(bytes, N, s * (u64)SUB, in.regs);
+    const u64 b = s * (u64)SUB_BLOCKS + (lane >> 1);
+    if (!passthrough) sub_load(bytes, N, s * (u64)SUB, in.regs);   // nothing is copied when the denoiser is off
     const u32 r0 = sub_rs_fetch(offsets, rec_lo_w, R, s, in.rf);
     in.rec0 = r0;
-    Plan z = {0, 0, 0, 0};
-    in.pl = z;
-    in.pfx = 0;
-    if (!PASSTHROUGH) {
-        in.pfx = plan.pfx_mask[s];
-        if (b < nB) { const PlanCT ct = plan.ct[b]; in.pl.C = ct.C; in.pl.TOK = ct.TOK; }
-    }
+    const PlanCT z = {0, 0};
+    in.ct = z;
+    if (b < nB) in.ct = plan.ct[b];
+    in.pfx = passthrough ? 0u : (u32)(plan.pfx_mask[s >> 1] >> (32 * (s & 1)));
     in.prev_w = in.next_w = 0;
     in.prev_rec = 0;
     if (lane == 0 && b > 0) {
         if (r0 > 0) in.prev_rec = (u32)offsets[r0 - 1];
-        if (!PASSTHROUGH) in.prev_w = plan.ct[b - 1].TOK & plan.ct[b - 1].C;
+        in.prev_w = plan.ct[b - 1].TOK & plan.ct[b - 1].C;
     }
-    if (!PASSTHROUGH && lane == 63 && b + 1 < nB) in.next_w = plan.ct[b + 1].TOK & plan.ct[b + 1].C;
+    if (lane == 63 && b + 1 < nB) in.next_w = plan.ct[b + 1].TOK & plan.ct[b + 1].C;
     in.base = tile_base[s];
 }
 
@@ -1686,14 +1658,19 @@ __device__ inline u32 wave_incl_scan_max(u32 v) {
     v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
     return v;
 }
+__device__ inline u32 below32(u32 j) { return j >= 32 ? ~0u : ((1u << j) - 1u); }   // bits < j
 
-// One wavefront per workgroup and sub-tile (4 KiB).  Nothing crosses wavefronts, so there are no workgroup
-// barriers: a wavefront only orders its own LDS traffic, and the waves of a CU drift apart and overlap each
-// other's load, compute and store phases.  (Several sub-tiles per wavefront with the loads of the next one in
-// flight were measured slower, 0.93 ms for one against 1.01 ms for eight on 1 GB of English text: fresh
+// One wavefront per workgroup and sub-tile (2 KiB), one lane per 32 bytes.  Nothing crosses wavefronts, so there
+// are no workgroup barriers: a wavefront only orders its own LDS traffic, and the waves of a CU drift apart and
+// overlap each other's load, compute and store phases.  The kernel is latency-bound: its time falls with the
+// number of resident waves (1.05 / 0.83 / 0.75 / 0.69 ms at 9 / 12 / 15 / 18 waves per CU with 64-byte lanes on
+// 1 GB of English text), hence the small lanes: 4.4 KB of LDS and about 50 VGPRs per wave allow 8 per SIMD.
+// (Several sub-tiles per wavefront with the loads of the next one in flight were measured slower: fresh
 // wavefronts hide the load latency better than the registers a prefetch holds.)
+// PASSTHROUGH: the denoiser is off, the text is the input itself: nothing is copied, k_count_tokens has left the
+// token plane in the plan.
 template <bool PASSTHROUGH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_emit(const u8* __restrict__ bytes,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_emit(const u8* __restrict__ bytes,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
                                               u64 N, u64 nB, u64 nW, PlanMem plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
@@ -1704,100 +1681,82 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     const u64 t = blockIdx.x;
     SubRs& srs = *reinterpret_cast<SubRs*>(sh.out);
     EmitIn in;
-    emit_fetch<PASSTHROUGH>(bytes, offsets, rec_lo_w, R, plan, tile_base, N, nB, t, in);
+    emit_fetch(bytes, offsets, rec_lo_w, R, plan, tile_base, N, nB, t, PASSTHROUGH, in);
     const u32 rec0 = uni(in.rec0), rec_n = uni(in.rf.n);   // records [rec0, rec0 + rec_n) start in this sub-tile
-    {
     const u64 tS = t * (u64)SUB;
-    const u64 b = t * (u64)SUB_BLOCKS + tid;
-    sub_store(in.regs, sh.tile.bytes);
+    const u64 b = t * (u64)SUB_BLOCKS + (tid >> 1);   // the lane's block; it owns half `hi` of it
+    const int hi = tid & 1;
+    // the separator planes of the few blocks that have them: a second, dependent load, issued before the
+    // sub-tile is stored to LDS
+    PlanPX px = {0, 0};
+    if (!PASSTHROUGH && ((in.pfx >> (tid >> 1)) & 1u) && b < nB) px = plan.px[b];
+    if (!PASSTHROUGH) sub_store(in.regs, sh.tile.bytes);
     sub_rs_store(in.rf, offsets, rec_lo_w, R, N, t, srs);
-    const PadBlk blk = lane_block_sub(sh.tile, tid);
-    const u64 p = tS + (u64)tid * BLOCK;
-    const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)BLOCK ? (N - p) : (u64)BLOCK);
-    const u64 V = below(nvalid);
-    // the separator planes of the few blocks that have them: a second, dependent load, issued before the tile
-    // is stored to LDS
-    if (!PASSTHROUGH && ((in.pfx >> tid) & 1ull) && b < nB) { const PlanPX px = plan.px[b]; in.pl.PSP = px.PSP; in.pl.PNL = px.PNL; }
-    Plan pl = in.pl;
-    if (nvalid == 0) { Plan z = {0, 0, 0, 0}; pl = z; }
+    const u8* blk = sh.tile.bytes + tid * HALF_STRIDE;
+    const u64 p = tS + (u64)tid * HALF;
+    const int nvalid = p >= N ? 0 : (int)((N - p) < (u64)HALF ? (N - p) : (u64)HALF);
+    const u32 V = below32((u32)nvalid);
+    const u32 Cm = (u32)(in.ct.C >> (32 * hi)) & V;
+    const u32 TOKC = (u32)(in.ct.TOK >> (32 * hi)) & Cm;
+    const u32 PSP = (u32)(px.PSP >> (32 * hi)), PNL = (u32)(px.PNL >> (32 * hi));
+    const u32 PFX = (PSP | PNL) & Cm;
     const u64 prev_w = in.prev_w, prev_rec = in.prev_rec;
-    bool edge_prev = false, edge_next = (in.next_w & 1ull) != 0;
+    const bool edge_prev = tid == 0 && (prev_w >> 63) != 0, edge_next = (in.next_w & 1ull) != 0;
     const u64 tb64 = (u64)uni((u32)in.base) | ((u64)uni((u32)(in.base >> 32)) << 32);   // the same in every lane
     wave_lds_sync();
-    const u64 RS = srs.w[tid] & V;
-    const bool next_rs = !(p + BLOCK < N) || (srs.w[tid + 1] & 1ull);
+    const u32 RS = srs.w[tid] & V;
+    const bool next_rs = !(p + HALF < N) || (srs.w[tid + 1] & 1u);
     wave_lds_sync();   // the record-start words are in registers: their space is the output image from here on
     // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every sub-tile after that phase
     if (stop_after == 1) return;
-    if (PASSTHROUGH) {
-        Cls c = {classify_ws_fast(blk, nvalid), 0, 0, 0, 0, 0, 0};
-        pl = plan_passthrough(c, V);
-        if (tid == 0 && b > 0) edge_prev = !byte_is_ws(blk, -1);
-        if (tid == 63 && p + BLOCK < N) edge_next = !byte_is_ws(blk, BLOCK);
-    } else if (tid == 0) {
-        edge_prev = (prev_w >> 63) != 0;
-    }
-    const u64 TOKC = pl.TOK & pl.C;
-    const u64 PFX = (pl.PSP | pl.PNL) & pl.C;
     // the neighbours' edge bits through the cross-lane network
-    const u32 up = (u32)__shfl_up((int)(u32)(TOKC >> 63), 1, 64), down = (u32)__shfl_down((int)(u32)(TOKC & 1ull), 1, 64);
+    const u32 up = (u32)__shfl_up((int)(TOKC >> 31), 1, 64), down = (u32)__shfl_down((int)(TOKC & 1u), 1, 64);
     const bool prev_tok = tid > 0 ? up != 0 : edge_prev;
     const bool next_tok = tid < 63 ? down != 0 : edge_next;
-    const u64 TS = token_starts(TOKC, RS, prev_tok);
-    const u64 TE = token_ends(TOKC, RS, next_tok, next_rs);
+    const u32 TS = TOKC & (~((TOKC << 1) | (prev_tok ? 1u : 0u)) | RS);
+    const u32 TE = TOKC & (~((TOKC >> 1) | (next_tok ? 0x80000000u : 0u)) | ((RS >> 1) | (next_rs ? 0x80000000u : 0u)));
     // wave prefix sums: emitted bytes | token starts << 16, token ends; prefix maximum: last token start + 1
-    const u32 me_nb = popc(pl.C) + popc(PFX), me_ntk = popc(TS), me_nte = popc(TE);
+    const u32 me_nb = (u32)__builtin_popcount(Cm) + (u32)__builtin_popcount(PFX), me_ntk = (u32)__builtin_popcount(TS),
+              me_nte = (u32)__builtin_popcount(TE);
     const u32 me_a = me_nb | (me_ntk << 16);
     const u32 inc_a = wave_incl_scan_add(me_a), inc_e = wave_incl_scan_add(me_nte);
-    const u32 inc_l = wave_incl_scan_max(TS ? (u32)(tid * BLOCK + top(TS) + 1) : 0u);
+    const u32 inc_l = wave_incl_scan_max(TS ? (u32)(tid * HALF + 31 - __builtin_clz(TS) + 1) : 0u);
     const u32 out0 = PASSTHROUGH ? (u32)tS : (u32)(tb64 & 0xFFFFFFFFull);   // output position of the sub-tile's first byte
     const u32 tok0 = (u32)(tb64 >> 32);                                      // index of the first token that starts in it
     const u32 ex_a = inc_a - me_a;
-    const u32 ex_nb = (PASSTHROUGH ? 0u : out0) + (ex_a & 0xFFFFu), ex_ntk = tok0 + (ex_a >> 16);
+    const u32 ex_nb = out0 + (ex_a & 0xFFFFu), ex_ntk = tok0 + (ex_a >> 16);
     const u32 up_l = (u32)__shfl_up((int)inc_l, 1, 64);   // every lane takes part
     const u32 ex_l = tid > 0 ? up_l : 0u;
-    const int ex_lts = (int)ex_l - 1;   // sub-tile-relative position of the last token start before this block, -1 none
+    const int ex_lts = (int)ex_l - 1;   // sub-tile-relative position of the last token start before this lane, -1 none
     const u32 tot_a = readlane_u32(inc_a, 63), tot_nte = readlane_u32(inc_e, 63);
-    const u32 total_nb = (PASSTHROUGH ? 0u : out0) + (tot_a & 0xFFFFu);
-    (void)inc_e;
+    const u32 total_nb = out0 + (tot_a & 0xFFFFu);
     const u32 shift = PASSTHROUGH ? 0 : (out0 & 15u);
     // does a token run into this sub-tile from the left?  Lane 0 finds where it starts.
-    const bool runs_in = readlane_u32((u32)(((TOKC & 1ull) && prev_tok && !(RS & 1ull)) ? 1u : 0u), 0) != 0;
+    const bool runs_in = readlane_u32((u32)(((TOKC & 1u) && prev_tok && !(RS & 1u)) ? 1u : 0u), 0) != 0;
     if (tid == 0 && runs_in) {
-        long long at = -1;   // start position inside the previous block, if it can be told from there
         // the last record that starts before the sub-tile, as a position in the previous block (or -1)
         const long long rp = (prev_rec + 64 >= tS && prev_rec < tS) ? (long long)(prev_rec + 64 - tS) : -1;
-        if (PASSTHROUGH) {
-            for (int k = 1; k <= 12; k++) {
-                if (rp == 64 - k) { at = 64 - k; break; }
-                if (byte_is_ws(blk, -k - 1)) { at = 64 - k; break; }
-            }
-        } else {
-            u64 zeros = ~prev_w;   // bit 63 of prev_w is set
-            long long z = zeros ? top(zeros) + 1 : -1;
-            at = z > rp ? z : rp;
-        }
-        if (at >= 0) sh.cin_start = (b - 1) * 64 + (u64)at;
-        else sh.cin_start = find_token_start_before<PASSTHROUGH>(bytes, N, plan.ct, tS, prev_rec);
+        const u64 zeros = ~prev_w;   // bit 63 of prev_w is set
+        const long long z = zeros ? top(zeros) + 1 : -1;
+        const long long at = z > rp ? z : rp;   // start position inside the previous block, if it can be told from there
+        if (at >= 0) sh.cin_start = tS - 64 + (u64)at;
+        else sh.cin_start = find_token_start_before(plan.ct, tS, prev_rec);
     }
     if (stop_after == 2) return;
     // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes
-    // with no separator inside; its source is contiguous in the lane's block and its destination is
+    // with no separator inside; its source is contiguous in the lane's half block and its destination is
     // contiguous in the output image, so it moves as (unaligned source, aligned destination) dwords.
-    // Lanes start their runs at different dwords so that the stride-64 pattern spreads over the banks.
     if (!PASSTHROUGH) {
-        const u8* src0 = blk.p;
         u32 o = ex_nb - out0 + shift;
-        u64 Cm = pl.C;
-        u64 brk = Cm & (PFX | ~(Cm << 1));
+        u32 brk = Cm & (PFX | ~(Cm << 1));
         while (brk) {
-            int a0 = ctz(brk);
+            const u32 a0 = (u32)__builtin_ctz(brk);
             brk &= brk - 1;
-            u64 rest = ~Cm >> a0;
-            u32 len = rest ? (u32)ctz(rest) : (u32)(64 - a0);
-            if (brk) { u32 nb = (u32)ctz(brk) - (u32)a0; if (nb < len) len = nb; }
-            if ((PFX >> a0) & 1) { sh.out[o] = ((pl.PNL >> a0) & 1) ? '\n' : ' '; o++; }
-            const u8* src = src0 + a0;
+            const u32 rest = ~Cm >> a0;
+            u32 len = rest ? (u32)__builtin_ctz(rest) : 32u - a0;
+            if (brk) { const u32 nbk = (u32)__builtin_ctz(brk) - a0; if (nbk < len) len = nbk; }
+            if ((PFX >> a0) & 1u) { sh.out[o] = ((PNL >> a0) & 1u) ? '\n' : ' '; o++; }
+            const u8* src = blk + a0;
             u8* dst = sh.out + o;
             u32 head = (4u - (o & 3u)) & 3u;
             if (head > len) head = len;
@@ -1806,16 +1765,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             // destination dwords are aligned; the source is read as aligned dwords and shifted in
             // registers (LDS accesses that straddle a dword stall the whole LDS pipeline).  Four dwords
             // at a time (five source dwords), the rest one by one.
-            const u32 sa = (u32)(a0 + head) & 3u;            // the block itself is dword aligned
+            const u32 sa = (a0 + head) & 3u;            // the half block itself is dword aligned
             const u8* sbase = src + head - sa;
             const u32 ng = nd >> 2;
-            const u32 grot = ((threadIdx.x & 3u) * ng) >> 2;
             for (u32 q = 0; q < ng; q++) {
-                u32 k = q + grot;
-                if (k >= ng) k -= ng;
-                const u32* sp = reinterpret_cast<const u32*>(sbase + 16 * k);
+                const u32* sp = reinterpret_cast<const u32*>(sbase + 16 * q);
                 const u32 w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
-                u32* dp = reinterpret_cast<u32*>(dst + head + 16 * k);
+                u32* dp = reinterpret_cast<u32*>(dst + head + 16 * q);
                 dp[0] = __builtin_amdgcn_alignbyte(w1, w0, sa);
                 dp[1] = __builtin_amdgcn_alignbyte(w2, w1, sa);
                 dp[2] = __builtin_amdgcn_alignbyte(w3, w2, sa);
@@ -1835,70 +1791,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // staged in LDS (the input image is no longer needed) and stored with coalesced writes below.
     u32* tokstage = reinterpret_cast<u32*>(sh.tile.bytes);
     {
-        const bool plain = PASSTHROUGH || (pl.C == V && PFX == 0);   // output position = ex_nb + bit index
-        auto outpos = [&](int j) -> u32 {   // output position of the (copied) byte at bit j
-            if (PASSTHROUGH) return (u32)p + (u32)j;
-            if (plain) return ex_nb + (u32)j;
-            return ex_nb + popc(pl.C & below(j)) + popc(PFX & below(j + 1));
+        // output position of the (copied) byte at bit j: the lane's base plus the bit index, minus the bytes
+        // dropped below j, plus the separators inserted up to j
+        const u32 base = PASSTHROUGH ? (u32)(p - tS) : ex_nb - out0;   // relative to out0
+        const u32 drops = PASSTHROUGH ? 0u : ~Cm, pfx = PASSTHROUGH ? 0u : PFX;
+        auto pos = [&](u32 j) -> u32 {
+            return base + j - (u32)__builtin_popcount(drops & ((1u << j) - 1u)) + (u32)__builtin_popcount(pfx & ((2u << j) - 1u));
         };
-        auto put = [&](u32 idx, u32 start_out, u32 len, bool inside) {
-            if (inside && idx - tok0 < TOK_CAP) tokstage[idx - tok0] = (start_out - out0) | (len << 16);
-            else { tok_start[idx] = start_out; tok_len[idx] = len; }
-        };
-        u64 ts = TS, te = TE;
-        u32 idx = ex_ntk;   // index of the next token that starts in this block
+        u32 ts = TS, te = TE;
+        u32 idx = ex_ntk;   // index of the next token that starts in this lane
         if (te) {
-            int x0 = ctz(te);
-            if (!ts || x0 < ctz(ts)) {
-                // the token that runs into this block from the left ends at x0
-                bool inside = ex_lts >= 0;
-                u64 start_abs = inside ? tS + (u64)ex_lts : sh.cin_start;
-                u32 len = (u32)(p + x0 - start_abs + 1);
-                put(idx - 1, outpos(x0) - (len - 1), len, inside);
+            const u32 x0 = (u32)__builtin_ctz(te);
+            if (!ts || x0 < (u32)__builtin_ctz(ts)) {
+                // the token that runs into this lane from the left ends at x0
+                const bool inside = ex_lts >= 0;
+                const u64 start_abs = inside ? tS + (u64)ex_lts : sh.cin_start;
+                const u32 len = (u32)(p + x0 - start_abs + 1);
+                const u32 start_rel = pos(x0) - (len - 1);   // relative to out0 (wraps below it when not inside)
+                if (inside && idx - 1 - tok0 < TOK_CAP) tokstage[idx - 1 - tok0] = start_rel | (len << 16);
+                else { tok_start[idx - 1] = out0 + start_rel; tok_len[idx - 1] = len; }
                 te &= te - 1;
             }
         }
-        // From here on starts and ends alternate.  The 64 bits are walked as two 32-bit halves, with the
-        // token that straddles the halves in between.  Output position of the byte at bit j: the bit
-        // index minus the bytes dropped below j plus the separators inserted up to j.
+        // from here on starts and ends alternate; a start without an end left belongs to a token that runs on
         const u32 slot0 = idx - tok0;
-        if (slot0 + (u32)popc(ts) <= TOK_CAP) {
+        if (slot0 + (u32)__builtin_popcount(ts) <= TOK_CAP) {
             u32* slot = tokstage + slot0;
-            const u32 base = PASSTHROUGH ? (u32)(p - tS) : ex_nb - out0;
-            const u64 drops = PASSTHROUGH ? 0ull : ~pl.C;
-            const u64 pfx = PASSTHROUGH ? 0ull : PFX;
-            const u32 dl = (u32)drops, dh = (u32)(drops >> 32), ql = (u32)pfx, qh = (u32)(pfx >> 32);
-            auto pos_lo = [&](u32 j) -> u32 {
-                return base + j - (u32)__builtin_popcount(dl & ((1u << j) - 1u)) + (u32)__builtin_popcount(ql & ((2u << j) - 1u));
-            };
-            const u32 base_hi = base + 32u - (u32)__builtin_popcount(dl) + (u32)__builtin_popcount(ql);
-            auto pos_hi = [&](u32 j) -> u32 {
-                return base_hi + j - (u32)__builtin_popcount(dh & ((1u << j) - 1u)) + (u32)__builtin_popcount(qh & ((2u << j) - 1u));
-            };
-            u32 tsl = (u32)ts, tsh = (u32)(ts >> 32), tel = (u32)te, teh = (u32)(te >> 32);
-            while (tel) {
-                const u32 x = (u32)__builtin_ctz(tel), s0 = (u32)__builtin_ctz(tsl);
-                tel &= tel - 1;
-                tsl &= tsl - 1;
-                *slot++ = pos_lo(s0) | ((x - s0 + 1u) << 16);
-            }
-            if (tsl && teh && (!tsh || __builtin_ctz(teh) < __builtin_ctz(tsh))) {
-                const u32 x = 32u + (u32)__builtin_ctz(teh), s0 = (u32)__builtin_ctz(tsl);
-                teh &= teh - 1;
-                *slot++ = pos_lo(s0) | ((x - s0 + 1u) << 16);
-            }
-            while (teh) {
-                const u32 x = (u32)__builtin_ctz(teh), s0 = (u32)__builtin_ctz(tsh);
-                teh &= teh - 1;
-                tsh &= tsh - 1;
-                *slot++ = pos_hi(s0) | ((x - s0 + 1u) << 16);
+            while (te) {
+                const u32 x = (u32)__builtin_ctz(te), s0 = (u32)__builtin_ctz(ts);
+                te &= te - 1;
+                ts &= ts - 1;
+                *slot++ = pos(s0) | ((x - s0 + 1u) << 16);
             }
         } else {
             while (te) {
-                int s0 = ctz(ts), x = ctz(te);
-                ts &= ts - 1;
+                const u32 x = (u32)__builtin_ctz(te), s0 = (u32)__builtin_ctz(ts);
                 te &= te - 1;
-                put(idx, outpos(s0), (u32)(x - s0 + 1), true);
+                ts &= ts - 1;
+                if (idx - tok0 < TOK_CAP) tokstage[idx - tok0] = pos(s0) | ((x - s0 + 1u) << 16);
+                else { tok_start[idx] = out0 + pos(s0); tok_len[idx] = x - s0 + 1u; }
                 idx++;
             }
         }
@@ -1930,8 +1861,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // per-record offsets
     {
         // lane i fetched the start of record rec0 + i with the sub-tile; a crowded sub-tile reads the rest.
-        // The record's block is another lane's: its words come through the cross-lane network (every lane takes
-        // part in every round).
+        // The record's half block is another lane's: its words come through the cross-lane network (every lane
+        // takes part in every round).
         for (u32 k0 = 0; k0 < rec_n; k0 += 64) {   // uniform
             const u32 k = k0 + (u32)tid;
             const u64 r = (u64)rec0 + k;
@@ -1939,13 +1870,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             u64 q = k0 == 0 ? (u64)in.rf.q : 0;
             if (k0 != 0 && have) q = offsets[r];
             const bool live = have && q < N && q >= tS;
-            const u32 l = live ? (u32)((q - tS) >> 6) & 63u : 0u, j = (u32)((q - tS) & 63);
-            const u64 lowm = below((int)j);
+            const u32 l = live ? (u32)((q - tS) >> 5) & 63u : 0u, j = (u32)((q - tS) & 31);
+            const u32 lowm = (1u << j) - 1u;
             const u32 eb = (u32)__shfl((int)ex_nb, (int)l, 64), tb = (u32)__shfl((int)ex_ntk, (int)l, 64);
-            const u64 cw = __shfl(pl.C, (int)l, 64), px = __shfl(PFX, (int)l, 64), ts = __shfl(TS, (int)l, 64);
+            const u32 cw = (u32)__shfl((int)Cm, (int)l, 64), pxm = (u32)__shfl((int)PFX, (int)l, 64),
+                      tsm = (u32)__shfl((int)TS, (int)l, 64);
             if (live) {
-                den_off[r] = PASSTHROUGH ? q : (u64)(eb + popc(cw & lowm) + popc(px & lowm));
-                tok_off[r] = (u64)(tb + popc(ts & lowm));
+                den_off[r] = PASSTHROUGH ? q : (u64)(eb + (u32)__builtin_popcount(cw & lowm) + (u32)__builtin_popcount(pxm & lowm));
+                tok_off[r] = (u64)(tb + (u32)__builtin_popcount(tsm & lowm));
             }
         }
     }
@@ -1956,8 +1888,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         const u64 g0 = (u64)out0 - shift;   // 16-aligned
         const u32 end = shift + n;
         for (u32 c16 = tid; c16 * 16 < end; c16 += 64) {
-            const u32 lo = c16 * 16, hi = lo + 16;
-            if (lo >= shift && hi <= end)
+            const u32 lo = c16 * 16, hi16 = lo + 16;
+            if (lo >= shift && hi16 <= end)
                 *reinterpret_cast<uint4*>(denoised + g0 + lo) = *reinterpret_cast<const uint4*>(sh.out + lo);
         }
         // the partial chunks at the two ends, one byte per lane: lanes 0-15 the first chunk, lanes 16-31 the last
@@ -1969,7 +1901,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             const u32 i = cl * 16 + (u32)tid - 16;
             if (end > 0 && cl > 0 && (end & 15u) != 0 && i < end) denoised[g0 + i] = sh.out[i];
         }
-    }
     }
 }
 
@@ -2595,8 +2526,8 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                  B.g3list, totals + 6, B.g3_cap, tbytes, ttoks, totals); }
         } else {
             Prof pr(c, "k_count_tokens");
-            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, tbytes, ttoks,
-                               tflags);
+            hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, plan, tbytes,
+                               ttoks, tflags);
         }
         { Prof pr(c, "scan_tiles");
           const GenTiles gen = {tbytes, ttoks, tflags, B.packed};
@@ -2670,9 +2601,9 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if ((rc = c->tok_len.ensure(tok_cap * sizeof(u32)))) return rc;
     if ((rc = c->chunks.ensure(chunk_cap * sizeof(ChunkDesc)))) return rc;
     if ((rc = c->totals.ensure(16 * sizeof(u64)))) return rc;
+    if ((rc = c->plan.ensure(plan_bytes(nB)))) return rc;
     if (!pass) {
         if ((rc = c->SA.ensure((nT + 1) * sizeof(J)))) return rc;
-        if ((rc = c->plan.ensure(plan_bytes(nB)))) return rc;
         if ((rc = c->denoised.ensure(N + 64))) return rc;
         if ((rc = c->seedJ.ensure((nT + 1) * sizeof(J)))) return rc;
         if ((rc = c->seedS.ensure((nT + 1) * sizeof(S)))) return rc;
