@@ -2170,7 +2170,7 @@ constexpr ScratchLayout scratch_layout() {
     L.end = at;
     return L;
 }
-constexpr size_t SCRATCH_BYTES = scratch_layout().end;   // about 24.6 MiB
+constexpr size_t SCRATCH_BYTES = scratch_layout().end;   // about 25 MiB
 static_assert(SCRATCH_BYTES <= ((size_t)32 << 20), "the fixed scratch array is meant to stay modest");
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
