@@ -198,6 +198,16 @@ struct WaveLines {
     FlagBallots xb, hb;
 };
 
+// The ballots of the record / line flags alone (what the short-line path below needs of WaveLines).
+__device__ inline void wave_ballots(const J& j, WaveLines& W) {
+    W.lsm = __ballot((j.g & G_LS) != 0);
+    W.rsm = __ballot((j.g & G_RS) != 0);
+    W.gah = __ballot((j.g & G_AH) != 0);
+    W.gat = __ballot((j.g & G_AT) != 0);
+    W.c0m = __ballot((j.g & G_C0) != 0);
+    W.c1m = __ballot((j.g & G_C1) != 0);
+}
+
 __device__ inline WaveLines wave_lines(const J& j) {
     WaveLines W;
     const bool has_ls = (j.g & G_LS) != 0;
@@ -267,6 +277,81 @@ __device__ inline J wave_range_total(const WaveLines& W, int lo, int hi) {
 }
 __device__ inline J wave_total(const WaveLines& W) { return wave_range_total(W, 0, 64); }
 
+// ---- the same carries for a wave of short lines -------------------------------------------------------
+// When every lane has a line start among the three lanes before it and among the three lanes after it (lines
+// of at most about 250 bytes: the usual case), a lane reaches everything it needs with three DPP shifts in each
+// direction: no prefix sums, no flag ballots.  A LineSum travels in one register: d | a << 8 | p << 16 | f << 24
+// (sums of up to three blocks stay below 256), with the block's "has a line start" flag at bit 29.
+constexpr u32 PK_LS = 1u << 29, PK_SUMS = 0x00FFFFFFu;
+__device__ inline u32 from_prev_lane(u32 v) {   // lane L reads lane L - 1, lane 0 reads 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);   // wave_shr:1
+}
+__device__ inline u32 from_next_lane(u32 v) {   // lane L reads lane L + 1, lane 63 reads 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);   // wave_shl:1
+}
+// ls_add over three packed parts of one line, a the earliest (absent parts are 0)
+__device__ inline u32 pk_join3(u32 a, u32 b, u32 c) {
+    constexpr u32 F = 3u << 24, LA = 12u << 24, SEEN = 16u << 24;
+    const u32 sums = (a & PK_SUMS) + (b & PK_SUMS) + (c & PK_SUMS);
+    const u32 first = (a & F) ? a : ((b & F) ? b : c);
+    const u32 last = (c & LA) ? c : ((b & LA) ? b : a);
+    return sums | (first & F) | (last & LA) | ((a | b | c) & SEEN);
+}
+__device__ inline LineSum unpack_pk(u32 v) {
+    LineSum r = {v & 0xFFu, (v >> 8) & 0xFFu, (v >> 16) & 0xFFu, (v >> 24) & 31u};
+    return r;
+}
+__device__ inline bool lines_are_near(u64 lsm) {   // uniform
+    const u64 back = (lsm << 1) | (lsm << 2) | (lsm << 3) | 0xFull;
+    const u64 fwd = (lsm >> 1) | (lsm >> 2) | (lsm >> 3) | (0xFull << 60);
+    return (back & fwd) == ~0ull;
+}
+struct NearLines {
+    u32 ci, co;        // the sums over the lanes of this wave only (packed)
+    u32 prev_ls;       // bit k: lane L - 1 - k has a line start (k = 0, 1)
+};
+__device__ inline NearLines near_lines(bool has_ls, u32 own_head, u32 own_tail) {
+    NearLines Q;
+    const u32 lsbit = has_ls ? PK_LS : 0u;
+    const u32 xp = (has_ls ? own_tail : own_head) | lsbit, hp = own_head | lsbit;
+    const u32 v1 = from_prev_lane(xp), v2 = from_prev_lane(v1), v3 = from_prev_lane(v2);
+    const bool b2 = !(v1 & PK_LS), b3 = b2 && !(v2 & PK_LS);
+    Q.ci = pk_join3(b3 ? v3 : 0u, b2 ? v2 : 0u, v1);
+    Q.prev_ls = ((v1 >> 29) & 1u) | ((v2 >> 28) & 2u);
+    const u32 u1 = from_next_lane(hp), u2 = from_next_lane(u1), u3 = from_next_lane(u2);
+    const bool f2 = !(u1 & PK_LS), f3 = f2 && !(u2 & PK_LS);
+    Q.co = pk_join3(u1, f2 ? u2 : 0u, f3 ? u3 : 0u);
+    return Q;
+}
+// the wave's summary (uniform); equals wave_total() of the general path
+__device__ inline J near_total(const WaveLines& W, const NearLines& Q, u32 own_head, u32 own_tail) {
+    J r;
+    const int f = ctz(W.lsm), l = top(W.lsm);
+    r.head = ls_add(unpack_pk(readlane_u32(Q.ci, f)), unpack_pk(readlane_u32(own_head, f)));
+    r.tail = ls_add(unpack_pk(readlane_u32(own_tail, l)), unpack_pk(readlane_u32(Q.co, l)));
+    u32 g = G_LS;
+    const bool c0l = (W.c0m >> l) & 1ull, c1l = (W.c1m >> l) & 1ull;
+    const u64 rs_before = W.rsm & below(l);
+    bool known;
+    if (rs_before) {
+        const int r0 = top(rs_before);
+        known = ((W.gat >> r0) & 1ull) || (W.gah & below(l) & ~below(r0 + 1)) != 0;
+    } else {
+        known = (W.gah & below(l)) != 0;
+        if (c1l) g |= G_C1;
+    }
+    if (c0l || (c1l && known)) g |= G_C0;
+    if (!W.rsm) {
+        if (W.gah) g |= G_AH | G_AT;
+    } else {
+        g |= G_RS;
+        if (W.gah & below(ctz(W.rsm) + 1)) g |= G_AH;
+        if (W.gat & ~below(top(W.rsm))) g |= G_AT;
+    }
+    r.g = g;
+    return r;
+}
+
 // Field-wise select on values (a select between two members of one struct would otherwise be turned
 // into an indexed load from a stack copy of the struct).
 __device__ inline u32 sel32(bool c, u32 a, u32 b) {
@@ -319,6 +404,41 @@ __device__ inline LaneCarry wave_carry(const WaveLines& W, const J& Pw, const S&
     const u32 at_e_da = sel32(eb != 0, ze_da, all_da), at_e_p = sel32(eb != 0, ze_p, all_p);
     const LineSum fwd = unpack_ls(at_e_da - W.Ix_da, at_e_p - W.Ix_p, flags_of(W.hb, afterL & below(e + 1)));
     k.co = eb ? fwd : ls_add(fwd, Xw.head);
+    k.next_rs = next_rs;
+    return k;
+}
+
+// wave_carry() for a wave of short lines (lines_are_near): own_g = the lane's own J::g
+__device__ inline LaneCarry near_carry(const WaveLines& W, const NearLines& Q, u32 own_g, const J& Pw, const S& Xw,
+                                       bool next_rs) {
+    const int L = threadIdx.x & 63;
+    LaneCarry k;
+    const int f = ctz(W.lsm), l = top(W.lsm);
+    const bool pw_ar = (Pw.g & G_RS) ? (Pw.g & G_AT) != 0 : (Pw.g & G_AH) != 0;
+    // the record has an alphabetic char before this block
+    {
+        const u64 bn = below(L);
+        const u64 rb = W.rsm & bn;
+        if (rb) {
+            const int r = top(rb);
+            k.ar_in = ((W.gat >> r) & 1ull) || (W.gah & bn & ~below(r + 1)) != 0;
+        } else {
+            k.ar_in = pw_ar || (W.gah & bn) != 0;
+        }
+    }
+    // "the record has an alphabetic char before this line's start", as the lane that holds the line start sees it
+    const u32 rab_own = ((own_g & G_C0) != 0 || ((own_g & G_C1) != 0 && k.ar_in)) ? 1u : 0u;
+    const u32 r1 = from_prev_lane(rab_own), r2 = from_prev_lane(r1), r3 = from_prev_lane(r2);
+    const LineSum ci = unpack_pk(Q.ci);
+    if (L <= f) {   // no line start in this wave before the lane: the line comes in from the left
+        k.ci = ls_add(ls_select((Pw.g & G_LS) != 0, Pw.tail, Pw.head), ci);
+        k.ci_rab = (Pw.g & G_C0) != 0;
+    } else {
+        k.ci = ci;
+        k.ci_rab = ((Q.prev_ls & 1u) ? r1 : (Q.prev_ls & 2u) ? r2 : r3) != 0;
+    }
+    const LineSum co = unpack_pk(Q.co);
+    k.co = L >= l ? ls_add(co, Xw.head) : co;
     k.next_rs = next_rs;
     return k;
 }
@@ -1018,9 +1138,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const J own = lane_J(L.c, L.d);
     // the block's own head / tail statistics are used again by plan_block: parked in one register each
     const u32 own_head = pack_ls(own.head), own_tail = pack_ls(own.tail);
-    const WaveLines W = wave_lines(own);
+    WaveLines W;
+    NearLines Q = {};
+    wave_ballots(own, W);
+    const bool near = lines_are_near(W.lsm);   // uniform: the wave's lines are short
     {
-        const J wt = wave_total(W);
+        J wt;
+        if (near) {
+            Q = near_lines((own.g & G_LS) != 0, own_head, own_tail);
+            wt = near_total(W, Q, own_head, own_tail);
+        } else {
+            W = wave_lines(own);
+            wt = wave_total(W);
+        }
         if (lane == 0) sh.jscan[wave] = wt;
     }
     __syncthreads();   // also: every lane has classified its block, the byte image is free from here on
@@ -1037,7 +1167,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
             if (v > wu) Xw = s_combine(uniform_S(s_from_J(sh.jscan[v])), Xw);
         }
     }
-    LaneCarry k = wave_carry(W, Pw, Xw, L.next_rs);
+    LaneCarry k = near ? near_carry(W, Q, own.g, Pw, Xw, L.next_rs) : wave_carry(W, Pw, Xw, L.next_rs);
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
     bool head_g3 = false;   // the line that runs into this block is a digit-heavy line (marked at its first byte)
     Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
@@ -1114,39 +1244,41 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (stop_after == 6) return;
     u64 TOKC = pl.TOK;
     u64 PFX = (pl.PSP | pl.PNL) & pl.C;
-    sh.tokc[tid] = TOKC;
-    __syncthreads();
     // The counts are kept per sub-tile (= per half wavefront: 32 blocks).  A token that runs into a sub-tile from
     // the left is counted as a start by the sub-tile (GenTiles takes it back, from the flags).
-    bool prev_tok = (lane & (SUB_BLOCKS - 1)) > 0 && (sh.tokc[tid - 1] >> 63);
-    u64 TS = token_starts(TOKC, L.d.RS, prev_tok);
-    u32 nb = popc(pl.C) + popc(PFX), ntk = popc(TS), nmk = popc(marks);
-    const bool last_tok = __shfl((int)(u32)(TOKC >> 63), lane | (SUB_BLOCKS - 1), 64) != 0;   // last lane of the half
-#pragma unroll
-    for (int off = SUB_BLOCKS / 2; off > 0; off >>= 1) {   // sums over the lanes of each half, in lanes 0 and 32
-        nb += __shfl_down((int)nb, off, SUB_BLOCKS);
-        ntk += __shfl_down((int)ntk, off, SUB_BLOCKS);
-        nmk += __shfl_down((int)nmk, off, SUB_BLOCKS);
-    }
-    const u32 nmk_hi = (u32)__shfl((int)nmk, SUB_BLOCKS, 64);
-    if (lane == 0) sh.red[2][wave] = nmk + nmk_hi;
-    if ((lane & (SUB_BLOCKS - 1)) == 0) {
+    const u32 left_tok = from_prev_lane((u32)(TOKC >> 63));   // read by every lane: a lane outside a branch is no source
+    const bool prev_tok = (lane & (SUB_BLOCKS - 1)) > 0 && left_tok != 0;
+    const u64 TS = token_starts(TOKC, L.d.RS, prev_tok);
+    // bytes (<= 128 per block) and token starts (<= 32 per block) summed over each half in one register:
+    // row prefix sums, then the totals of rows 0 and 2 added into rows 1 and 3 - lanes 31 and 63 hold the sums
+    u32 cnt = (popc(pl.C) + popc(PFX)) | (popc(TS) << 16);
+    cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x111, 0xf, 0xf, false);   // row_shr:1
+    cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x112, 0xf, 0xf, false);   // row_shr:2
+    cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x114, 0xf, 0xf, false);   // row_shr:4
+    cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x118, 0xf, 0xf, false);   // row_shr:8
+    cnt += (u32)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    const u64 first_cont = __ballot((TOKC & 1ull) && !(L.d.LS & 1ull));   // bits 0 and 32: the halves' first blocks
+    const u64 left_m = __ballot(marks != 0);
+    if (lane == 0) sh.red[2][wave] = left_m != 0 ? 1u : 0u;
+    if ((lane & (SUB_BLOCKS - 1)) == SUB_BLOCKS - 1) {
         const u64 sub = b / SUB_BLOCKS;
         if (sub * (u64)SUB < N) {
-            tile_bytes[sub] = nb;
-            tile_toks[sub] = ntk;
+            tile_bytes[sub] = cnt & 0xFFFFu;
+            tile_toks[sub] = cnt >> 16;
             u32 f = 0;
-            if ((TOKC & 1ull) && !(L.d.LS & 1ull)) f |= TF_FIRST_CONT;
-            if (last_tok) f |= TF_LAST_TOK;
+            if ((first_cont >> (lane - (SUB_BLOCKS - 1))) & 1ull) f |= TF_FIRST_CONT;
+            if (TOKC >> 63) f |= TF_LAST_TOK;
             tile_flags[sub] = f;
         }
     }
     __syncthreads();
     u32 sm = 0;
-    for (int w = 0; w < NT / 64; w++) sm += sh.red[2][w];
+    for (int w = 0; w < NT / 64; w++) sm |= sh.red[2][w];
     if (sm > 0) {   // uniform, rare: lines left for k_gate3_solve go to the global work list
-        if (tid == 0) sh.g3base = atomicAdd(reinterpret_cast<unsigned long long*>(g3count), (unsigned long long)sm);
-        u32 at = block_scan_excl_fwd((u32)popc(marks), U32Add(), 0u, 0u, sh.scan32, (u32*)nullptr);   // barriers inside
+        u32 tot = 0;
+        const u32 at = block_scan_excl_fwd((u32)popc(marks), U32Add(), 0u, 0u, sh.scan32, &tot);   // barriers inside
+        if (tid == 0) sh.g3base = atomicAdd(reinterpret_cast<unsigned long long*>(g3count), (unsigned long long)tot);
+        __syncthreads();
         u64 pos = sh.g3base + at;
         for (u64 m = marks; m; m &= m - 1, pos++) {
             const int jb = ctz(m);
