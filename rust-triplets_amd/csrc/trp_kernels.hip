@@ -604,6 +604,16 @@ __device__ inline u64 block_record_starts(const u64* __restrict__ offsets, const
     return bits;
 }
 
+// The blocks next to a lane's block are the blocks of the lanes next to it (trp_lane.h, NoNeighbours).
+struct WaveNeighbours {
+    __device__ bool any(bool x) const { return __ballot(x) != 0; }
+    __device__ bool has_next() const { return (threadIdx.x & 63) < 63; }
+    __device__ bool has_prev() const { return (threadIdx.x & 63) > 0; }
+    template <class B>
+    __device__ u32 next_planes3(u32 mine, const B&) const { return from_next_lane(mine); }
+    __device__ u32 swap_spill(u32 v) const { return from_prev_lane(v); }
+};
+
 struct LaneCtx {
     Cls c;
     Derived d;
@@ -627,7 +637,8 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
         L.c = z;
         L.nl = 0;
     } else {
-        L.c = classify_block_fast(blk, L.nvalid, ut);
+        WaveNeighbours nb;   // every lane of the wavefront is here, lane i with block i of its 64
+        L.c = classify_block_fast(blk, L.nvalid, ut, nb);
         L.sp = L.c.sp;
         L.nl = L.c.nl;
     }
@@ -1135,6 +1146,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
     LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w[tid], sh.rs.w[tid + 1], NORMALIZE);
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
+    // The ' ' and '\n' bytes are needed once more, at the very end (plan_fold_prefixes): parked in LDS in one
+    // mask until then.  A '\n' is a terminator and a ' ' is line content, which tells them apart again.
+    if (!NORMALIZE) sh.tokc[tid] = L.c.sp | L.c.nl;
     const J own = lane_J(L.c, L.d);
     // the block's own head / tail statistics are used again by plan_block: parked in one register each
     const u32 own_head = pack_ls(own.head), own_tail = pack_ls(own.tail);
@@ -1171,7 +1185,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
     bool head_g3 = false;   // the line that runs into this block is a digit-heavy line (marked at its first byte)
     Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
-                        : plan_block(L.c, L.d, k, cfg, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3);
+                        : plan_block(L.c, L.d, k, cfg, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3, false);
+    if (!NORMALIZE) {
+        const u64 sp_nl = sh.tokc[tid];
+        plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, L.d.V);
+    }
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -1194,11 +1212,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         gm.ls[tid] = L.d.LS;
         gm.G[tid] = 0; gm.gPSP[tid] = 0; gm.gPNL[tid] = 0;
         sh.marks[tid] = marks;
-        // parked in LDS across the solve (registers are short there): the ' ' and '\n' masks.  Both arrays
-        // are free here: the record starts were consumed by lane_setup before the barriers above, the
-        // token masks are written after the plan is stored.
-        sh.tokc[tid] = L.sp;
-        sh.rs.w[tid] = L.nl;
         u32 nm = popc(marks), tot = 0;
         u32 at = block_scan_excl_fwd(nm, U32Add(), 0u, 0u, sh.scan32, &tot);   // ends with a barrier
         if (tot > 0) {   // uniform
@@ -1225,7 +1238,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
             pl.C |= gm.G[tid];
             pl.TOK |= gm.G[tid];
             marks = left;
-            plan_fold_prefixes(pl, sh.tokc[tid], sh.rs.w[tid], below(L.nvalid));   // the separators of the kept tokens
+            {   // the separators of the kept tokens
+                const u64 sp_nl = sh.tokc[tid];
+                plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, below(L.nvalid));
+            }
         }
     }
     if (stop_after == 5) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }

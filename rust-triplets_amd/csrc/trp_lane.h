@@ -289,14 +289,31 @@ TRP_HD u32 planes_ge(const u32 (&b)[6], u32 c) {
 }
 TRP_HD u32 planes_in(const u32 (&b)[6], u32 lo, u32 hi) { return planes_ge(b, lo) & ~planes_ge(b, hi + 1u); }
 // *ws2 / *ws3 receive the lead bytes of the two- and three-byte White_Space characters among the settled ones.
-TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead, u32* alp, u32* ws2, u32* ws3) {
+// The planes that follow a half: a full word per plane (the other half of the block) ...
+struct PlanesAfter {
+    const u32* q;
+    TRP_HD u32 operator()(int k) const { return q[k]; }
+};
+// ... or only the first three bytes of the next block, plane k in bits 3k .. 3k+2 of one word.
+struct PlanesAfter3 {
+    u32 packed;
+    TRP_HD u32 operator()(int k) const { return (packed >> (3 * k)) & 7u; }
+};
+TRP_HD u32 pack_planes3(const u32 (&lo)[8]) {
+    u32 r = lo[0] & 7u;
+    TRP_UNROLL
+    for (int k = 1; k < 8; k++) r |= (lo[k] & 7u) << (3 * k);
+    return r;
+}
+template <class Q>
+TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const Q& q, u32 lead, u32* alp, u32* ws2, u32* ws3) {
     if (!lead) return 0;
-    const u32 cont = p[7] & ~p[6], contq = q[7] & ~q[6];
+    const u32 cont = p[7] & ~p[6], contq = q(7) & ~q(6);
     const u32 v1 = funnel_shr(contq, cont, 1), v2 = funnel_shr(contq, cont, 2), v3 = funnel_shr(contq, cont, 3);
     const u32 l0 = p[0], l1 = p[1], l2 = p[2], l3 = p[3], l4 = p[4];
     // low six bits of the second (x) and third (y) byte, aligned to the lead byte
-    const u32 x0 = funnel_shr(q[0], p[0], 1), x1 = funnel_shr(q[1], p[1], 1), x2 = funnel_shr(q[2], p[2], 1),
-              x3 = funnel_shr(q[3], p[3], 1), x4 = funnel_shr(q[4], p[4], 1), x5 = funnel_shr(q[5], p[5], 1);
+    const u32 x0 = funnel_shr(q(0), p[0], 1), x1 = funnel_shr(q(1), p[1], 1), x2 = funnel_shr(q(2), p[2], 1),
+              x3 = funnel_shr(q(3), p[3], 1), x4 = funnel_shr(q(4), p[4], 1), x5 = funnel_shr(q(5), p[5], 1);
     const u32 x_ge16 = x5 | x4;
     u32 settled = 0, alpha = 0;
     const u32 L2 = lead & ~p[5] & v1;   // 110xxxxx 10xxxxxx
@@ -341,8 +358,8 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead,
     const u32 L3 = lead & p[5] & ~p[4] & v1 & v2;   // 1110xxxx 10xxxxxx 10xxxxxx
     const u32 L4 = lead & p[5] & p[4] & ~p[3] & v1 & v2 & v3;
     if (L3 | L4) {
-        const u32 y0 = funnel_shr(q[0], p[0], 2), y1 = funnel_shr(q[1], p[1], 2), y2 = funnel_shr(q[2], p[2], 2),
-                  y3 = funnel_shr(q[3], p[3], 2), y4 = funnel_shr(q[4], p[4], 2), y5 = funnel_shr(q[5], p[5], 2);
+        const u32 y0 = funnel_shr(q(0), p[0], 2), y1 = funnel_shr(q(1), p[1], 2), y2 = funnel_shr(q(2), p[2], 2),
+                  y3 = funnel_shr(q(3), p[3], 2), y4 = funnel_shr(q(4), p[4], 2), y5 = funnel_shr(q(5), p[5], 2);
         const u32 E5_E9 = L3 & ((~l3 & l2 & (l1 | l0)) | (l3 & ~l2 & ~l1));         // U+5000-9FFF
         const u32 E4 = L3 & ~l3 & l2 & ~l1 & ~l0;                                   // U+4000-4FFF
         const u32 E3 = L3 & ~l3 & ~l2 & l1 & l0;                                    // U+3000-3FFF
@@ -394,8 +411,46 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const u32 (&q)[8], u32 lead,
     return settled;
 }
 
-template <class B>
-TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut) {
+// What a block may learn from the blocks next to it while it is being classified.  The blocks of a group are
+// classified together (the lanes of a wavefront) or one after the other in ascending order (the host simulator);
+// a block at the edge of its group has no neighbour on that side and falls back on reading the bytes itself.
+//   any(x)            x for any block of the group (every block of the group makes the calls below, or none)
+//   has_next()        the next block belongs to the group; next_planes3(mine, blk): the bit planes of the first
+//                     three bytes of the next block as pack_planes3() packs them (mine = this block's own)
+//   has_prev()        the previous block belongs to the group; swap_spill(v) hands v to the next block and
+//                     returns what the previous block handed over (0 without one)
+struct NoNeighbours {
+    TRP_HD bool any(bool x) const { return x; }
+    TRP_HD bool has_next() const { return false; }
+    TRP_HD bool has_prev() const { return false; }
+    template <class B>
+    TRP_HD u32 next_planes3(u32, const B&) const { return 0; }
+    TRP_HD u32 swap_spill(u32) const { return 0; }
+};
+// Blocks classified one after the other in ascending order (host code): the planes of the next block are built
+// from its first three bytes, the spill is kept from one call to the next.
+struct SeqNeighbours {
+    bool first = true, last = false;   // set by the caller before each block
+    u32 kept = 0;
+    bool any(bool) const { return true; }
+    bool has_next() const { return !last; }
+    bool has_prev() const { return !first; }
+    template <class B>
+    u32 next_planes3(u32, const B& blk) const {
+        u32 r = 0;
+        for (int k = 0; k < 8; k++)
+            for (int j = 0; j < 3; j++) r |= (((u32)blk[64 + j] >> k) & 1u) << (3 * k + j);
+        return r;
+    }
+    u32 swap_spill(u32 v) {
+        const u32 r = first ? 0u : kept;
+        kept = v;
+        return r;
+    }
+};
+
+template <class B, class X>
+TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut, X& nb) {
     u32 w[16];
 TRP_UNROLL
     for (int k = 0; k < 16; k++) w[k] = blk.word(k);
@@ -404,24 +459,43 @@ TRP_UNROLL
     const u64 V = below(nvalid);
     // Bytes >= 0x80 first (few values are live here).  Only lead bytes (11xxxxxx) are decoded; a
     // whitespace character marks all its bytes, an alphabetic one its lead byte.  Continuation bytes at
-    // the very start of the block belong to a character that began in the previous block and are resolved
-    // by looking back.
+    // the very start of the block belong to a character that began in the previous block: the previous
+    // block says whether they are whitespace when it has settled that character, otherwise they are
+    // resolved by looking back.
     u64 mb_ws = 0, mb_alp = 0;
     const u64 high = b[7] & V;
     u64 lead = high & b[6];
-    if (lead) {
-        // the common scripts from the bit planes, half a block at a time
-        u32 lo[8], hi[8], zero[8];
+    bool look_back = true;
+    if (nb.any(high != 0)) {
+        u32 lo[8], hi[8];
 TRP_UNROLL
-        for (int k = 0; k < 8; k++) { lo[k] = (u32)b[k]; hi[k] = (u32)(b[k] >> 32); zero[k] = 0; }
-        u32 alp_lo = 0, alp_hi = 0, ws2_lo = 0, ws2_hi = 0, ws3_lo = 0, ws3_hi = 0;
-        const u32 s_lo = classify_leads_planes(lo, hi, (u32)lead, &alp_lo, &ws2_lo, &ws3_lo);
-        const u32 s_hi = classify_leads_planes(hi, zero, (u32)(lead >> 32) & 0x1FFFFFFFu, &alp_hi, &ws2_hi, &ws3_hi);   // ends by byte 63
-        mb_alp = (u64)alp_lo | ((u64)alp_hi << 32);
-        lead &= ~((u64)s_lo | ((u64)s_hi << 32));
-        // a whitespace character marks all its bytes
-        const u64 w3 = (u64)ws3_lo | ((u64)ws3_hi << 32), w23 = w3 | (u64)ws2_lo | ((u64)ws2_hi << 32);
-        mb_ws = (w23 | (w23 << 1) | (w3 << 2)) & V;
+        for (int k = 0; k < 8; k++) { lo[k] = (u32)b[k]; hi[k] = (u32)(b[k] >> 32); }
+        // with the planes of the next block's first bytes every sequence that begins in this block is seen whole,
+        // without them the second half takes the sequences that end by byte 63
+        const PlanesAfter3 after = {nb.next_planes3(pack_planes3(lo), blk)};
+        const bool has_next = nb.has_next();
+        u32 spill = 0;
+        if (lead) {
+            // the common scripts from the bit planes, half a block at a time
+            u32 alp_lo = 0, alp_hi = 0, ws2_lo = 0, ws2_hi = 0, ws3_lo = 0, ws3_hi = 0;
+            const PlanesAfter second = {hi};
+            const u32 s_lo = classify_leads_planes(lo, second, (u32)lead, &alp_lo, &ws2_lo, &ws3_lo);
+            const u32 s_hi = classify_leads_planes(hi, after, (u32)(lead >> 32) & (has_next ? ~0u : 0x1FFFFFFFu), &alp_hi,
+                                                   &ws2_hi, &ws3_hi);
+            mb_alp = (u64)alp_lo | ((u64)alp_hi << 32);
+            lead &= ~((u64)s_lo | ((u64)s_hi << 32));
+            // a whitespace character marks all its bytes
+            const u64 w3 = (u64)ws3_lo | ((u64)ws3_hi << 32), w23 = w3 | (u64)ws2_lo | ((u64)ws2_hi << 32);
+            mb_ws = (w23 | (w23 << 1) | (w3 << 2)) & V;
+            // for the next block: its first / second byte continue a whitespace character of this block;
+            // bit 2: a character that may run over is still unsettled (the next block has to look back)
+            spill = (u32)(w23 >> 63) | ((u32)(w3 >> 62) & 1u) | ((u32)(w3 >> 63) << 1) | ((lead >> 61) ? 4u : 0u);
+        }
+        const u32 from_prev = nb.swap_spill(spill);
+        if (nb.has_prev()) {
+            mb_ws |= (u64)(from_prev & 3u) & V;
+            look_back = (from_prev & 4u) != 0;
+        }
     }
     while (lead) {
         const int j = ctz(lead);
@@ -449,7 +523,7 @@ TRP_UNROLL
         const u32 cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
         if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
     }
-    u64 head = high & ~b[6] & 7ull;   // continuation bytes among the first three
+    u64 head = look_back ? high & ~b[6] & 7ull : 0ull;   // continuation bytes among the first three
     for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
         u32 cp;
         for (int k = j + 1; k <= 3; k++) {   // the lead byte is before the block
@@ -479,6 +553,11 @@ TRP_UNROLL
     c.alp = (n7 & b[6] & nz5 & ~gt26) | mb_alp;                  // A-Z a-z
     c.pipe = n7 & b[6] & b[5] & b[4] & b[3] & b[2] & ~b[1] & ~b[0];   // 0x7C
     return c;
+}
+template <class B>
+TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut) {
+    NoNeighbours nb;
+    return classify_block_fast(blk, nvalid, ut, nb);
 }
 
 // The whitespace mask alone (what the pass-through configuration needs): no Alphabetic lookups at all.
@@ -811,8 +890,9 @@ TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
 // lane_J computes them (head and tail of the block's summary).
 // *head_g3 (optional): the line that runs into the block from an earlier one is a digit-heavy line; it is
 // marked in the block that holds its first byte, nothing of it is planned here.
+// fold = false leaves plan_fold_prefixes() to the caller.
 TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg, const LineSum& own_head,
-                       const LineSum& own_tail, bool* head_g3 = nullptr) {
+                       const LineSum& own_tail, bool* head_g3 = nullptr, bool fold = true) {
     Plan out = {0, 0, 0, 0};
     bool head_pending = false;
     const bool head0 = !(d.LS & 1ull);      // the block starts inside a line begun earlier
@@ -895,7 +975,7 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         const u64 R = below(ctz(d.LS & ~below(s + 1))) & ~below(s);   // a later line start exists
         line(s, R, false, range_sum(c, d, R));
     }
-    plan_fold_prefixes(out, c.sp, c.nl, d.V);
+    if (fold) plan_fold_prefixes(out, c.sp, c.nl, d.V);
     if (head_g3) *head_g3 = head_pending;
     return out;
 }

@@ -121,10 +121,13 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
     std::vector<Plan> plan(nB + 1, Plan{0, 0, 0, 0});
     std::vector<Cls> cls(nB);
     std::vector<u64> Vm(nB);
+    SeqNeighbours nb;   // groups of 64 blocks, like the lanes of a wavefront
     for (u64 b = 0; b < nB; b++) {
         u64 p = b * 64;
         int nvalid = (int)((N - p) < 64 ? (N - p) : 64);
-        cls[b] = classify_block_fast(PlainBlk{base + p}, nvalid, ut);
+        nb.first = b % 64 == 0;
+        nb.last = b % 64 == 63 || b + 1 == nB;
+        cls[b] = classify_block_fast(PlainBlk{base + p}, nvalid, ut, nb);
         {   // the bit-sliced classifier must agree with the byte-by-byte one
             Cls ref = classify_block(PlainBlk{base + p}, nvalid, ut);
             if (ref.ws != cls[b].ws || ref.nl != cls[b].nl || ref.cr != cls[b].cr || ref.pipe != cls[b].pipe ||
@@ -404,7 +407,7 @@ extern "C" int trp_sim_check_alpha_shortcut() {
 extern "C" int trp_sim_check_classify_codepoints() {
     UniTables ut = {trp_alpha_stage1, trp_alpha_stage2, TRP_ALPHA_STAGE1_LEN, nullptr};
     int bad = 0;
-    u8 buf[8 + 64 + 8];
+    u8 buf[8 + 128 + 8];
     static const int positions[] = {0, 33, 58, 60, 61, 62, 63};
     for (u32 cp = 0x80; cp < 0x110000; cp++) {
         if (cp >= 0xD800 && cp < 0xE000) continue;
@@ -424,6 +427,16 @@ extern "C" int trp_sim_check_classify_codepoints() {
                 if (f.ws != r.ws || f.alp != r.alp || f.nl != r.nl || f.cr != r.cr || f.pipe != r.pipe || f.dig != r.dig)
                     bad++;
                 if (classify_ws_fast(blk, 64) != r.ws) bad++;
+                // the same two blocks classified as neighbours of one group
+                SeqNeighbours nb;
+                for (int k = 0; k < 2; k++) {
+                    const PlainBlk bk = {buf + 8 + 64 * k};
+                    nb.first = k == 0;
+                    nb.last = k == 1;
+                    const Cls g = classify_block_fast(bk, 64, ut, nb), h = classify_block(bk, 64, ut);
+                    if (g.ws != h.ws || g.alp != h.alp || g.nl != h.nl || g.cr != h.cr || g.pipe != h.pipe || g.dig != h.dig)
+                        bad++;
+                }
             }
         }
     }
