@@ -312,6 +312,72 @@ def test_token_density_around_the_staged_table_of_a_sub_tile(T, ctx):
         assert_same(exp, ctx.normalize_batch(data, offs), recs, "token density, normalize")
 
 
+def test_line_lengths_around_the_short_line_carries(T, ctx):
+    """k_plan takes the line carries of a wavefront from its neighbouring lanes when every block has a line start
+    within three blocks on either side, and from prefix sums otherwise: line lengths below, at and above that
+    reach (in blocks of 64 bytes), wavefronts (4 KiB) that mix both, table rows and digit-heavy lines among them,
+    lines without a letter, records that start in the middle of such stretches."""
+    import random
+    rng = random.Random(5)
+
+    def line(n, kind):
+        if kind == 0:
+            words = "lorem ipsum dolor sit amet consectetur adipiscing elit sed do".split()
+        elif kind == 1:
+            words = "| cell | 12 | other cell | 3.5 |".split(" ")
+        elif kind == 2:
+            words = "2019 1,234 56.7 total 8 9 10".split()
+        else:
+            words = "12 34 -- 56 ++ 78".split()
+        out = []
+        size = 0
+        while size < n:
+            w = rng.choice(words)
+            out.append(w)
+            size += len(w) + 1
+        return " ".join(out)[:max(n, 1)]
+
+    recs = []
+    for lengths in ((60, 100), (180, 200), (190, 260), (250, 330), (60, 700), (1, 64), (120, 130)):
+        body = []
+        for i in range(400):
+            body.append(line(rng.randint(*lengths), rng.choice((0, 0, 0, 1, 2, 3))))
+            if rng.random() < 0.02:
+                recs.append("\n".join(body).encode())
+                body = []
+        recs.append("\n".join(body).encode())
+    # every block exactly one line of 63 bytes + terminator, then lines of exactly 192 and 256 bytes
+    recs.append(("\n".join("x" * 63 for _ in range(300))).encode())
+    recs.append(("\n".join(("y z " * 48)[:191] for _ in range(100))).encode())
+    recs.append(("\n".join(("y z " * 64)[:255] for _ in range(100))).encode())
+    for cfg in ((True, 0.35, True, 16, (4, 2), 8), (True, 0.9, False, 1024, (64,), 512)):
+        exp, got = _run(T, ctx, recs, cfg)
+        assert_same(exp, got, recs, "line lengths, ratio %s" % cfg[1])
+
+
+def test_characters_across_block_edges(T, ctx):
+    """Multi-byte characters placed so that they straddle the 64-byte blocks and the 4 KiB wavefront edges of the
+    classifier (which settles them with the first bytes of the next block): letters and whitespace characters of
+    two, three and four bytes at every offset against the block grid, in the scripts the range rules cover and in
+    scripts that take the per-character path; denoiser on and off."""
+    chars = ["\u00e9", "\u00a0", "\u0085", "\u03a9", "\u0416", "\u4e2d", "\u3000", "\u2028", "\u2003", "\u3042",
+             "\U0001f600", "\U00020000", "\u10d0", "\u1680", "\u0e01", "\u0915", "\uac00", "\u205f", "\ufeff"]
+    recs = []
+    for shift in range(0, 9):
+        parts = []
+        for i, ch in enumerate(chars * 12):
+            # the character lands near the end of a block: filler brings the running length to 64 k - (0..3)
+            cur = sum(len(x.encode()) for x in parts) + shift
+            pad = (-cur - (i % 4)) % 64
+            parts.append("a" * max(pad - 1, 0) + (" " if pad else "") + ch + ch + ("\n" if i % 7 == 0 else " "))
+        recs.append(("b" * shift + "".join(parts)).encode())
+    recs.append(("\u4e2d" * 3000).encode())
+    recs.append(("\u3000" * 700 + "x" + "\u00a0" * 500).encode())
+    for cfg in ((True, 0.35, True, 16, (4,), 8), (False, 0.35, True, 1024, (64,), 512)):
+        exp, got = _run(T, ctx, recs, cfg)
+        assert_same(exp, got, recs, "block edges, denoiser %s" % cfg[0])
+
+
 def test_inputs_produced_on_the_callers_stream_need_no_sync(T):
     """A context created on the caller's stream (here torch's current stream) is ordered after the
     asynchronous copies that produce its inputs; a context with a private stream gets the same ordering
