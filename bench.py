@@ -111,10 +111,13 @@ def roofline_of(kern, stats, nb, ms_per_step):
             "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}}
 
 
-def run_in_flight(T, device, batches, den, st, steps, warmup):
+def run_in_flight(T, device, batches, den, st, steps, warmup, stagger_s=0.0):
     """The same passes with one batch in flight on each of two contexts (trp_submit_batch_device /
     trp_wait_batch): the kernels of consecutive batches overlap, the way a consumer of one batch overlaps with
-    the production of the next.  Every batch of every pass is waited for inside the timed region."""
+    the production of the next.  Every batch of every pass is waited for inside the timed region.
+    stagger_s: the second context's first batch is submitted that much later than the first context's, so that
+    the two run out of phase (one batch's issue-bound planning beside the other's bandwidth-bound emit); the
+    delay is inside the timed region."""
     import torch
     cs = (T.Context(device), T.Context(device))
 
@@ -125,6 +128,10 @@ def run_in_flight(T, device, batches, den, st, steps, warmup):
                 j = i % 2
                 if busy[j]:
                     cs[j].wait_batch()
+                elif i == 1 and stagger_s > 0:
+                    t1 = time.perf_counter()
+                    while time.perf_counter() - t1 < stagger_s:
+                        pass
                 cs[j].submit_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
                 busy[j] = True
                 i += 1
@@ -142,7 +149,8 @@ def run_in_flight(T, device, batches, den, st, steps, warmup):
         c.close()
     N = sum(b[3] for b in batches)
     return {"value": round(N * steps / elapsed / 1e9, 2), "unit": "GB/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "steps": steps, "calls": "submit/wait, one batch in flight on each of two contexts"}
+            "steps": steps, "calls": "submit/wait, one batch in flight on each of two contexts"
+                                     + (", the second %.2f ms out of phase" % (stagger_s * 1e3) if stagger_s else "")}
 
 
 def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup):
@@ -404,6 +412,8 @@ def main():
         ex = {}
         keep_host = (data, offs)
         out["in_flight"] = run_in_flight(T, device, batches, den, st, max(args.steps, 10), 3)
+        out["in_flight_out_of_phase"] = run_in_flight(T, device, batches, den, st, max(args.steps, 10), 3,
+                                                      stagger_s=0.45 * out["ms_per_step"] / max(1, nb) * 1e-3)
 
         def to_dev(dd, oo):
             return (torch.from_numpy(dd).cuda(), torch.from_numpy(oo.astype(np.int64)).cuda(), int(len(oo) - 1), int(len(dd)))

@@ -624,9 +624,9 @@ struct LaneCtx {
     u64 sp, nl;     // bytes that are exactly ' ' / '\n' (for plan_fold_prefixes)
 };
 
-// rs_here / rs_next: record-start words of this block and of the next one (RsShared).
+// rs_words: record-start words of the tile's blocks (RsShared), complete before the call.
 __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, u64 N, u64 tS, bool want_lines,
-                                     u64 rs_here, u64 rs_next, bool normalize = false) {
+                                     const u64* rs_words, bool normalize = false) {
     LaneCtx L;
     const int tid = threadIdx.x;
     const PadBlk blk = lane_block(sh, tid);
@@ -642,6 +642,9 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
         L.sp = L.c.sp;
         L.nl = L.c.nl;
     }
+    // read only now: the classifier needs every register it can get
+    asm volatile("" ::: "memory");
+    const u64 rs_here = rs_words[tid], rs_next = rs_words[tid + 1];
     u64 V = below(L.nvalid);
     u64 RS = rs_here & V;
     bool nrs = (rs_next & 1ull) != 0;
@@ -721,8 +724,7 @@ __global__ __launch_bounds__(NT) void k_summary(const u8* __restrict__ bytes, co
             rs_store(rf, offsets, rec_lo, R, N, t, rs);
         }
         __syncthreads();
-        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs.w[threadIdx.x], rs.w[threadIdx.x + 1],
-                               NORMALIZE);
+        LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, true, rs.w, NORMALIZE);
         J j = wave_total(wave_lines(lane_J(L.c, L.d)));
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = j;
         __syncthreads();   // also: every lane has finished reading the image and the record starts
@@ -1144,7 +1146,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (tid == 64) sh.seed_s = seedS[t];
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
-    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w[tid], sh.rs.w[tid + 1], NORMALIZE);
+    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w, NORMALIZE);
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
     // The ' ' and '\n' bytes are needed once more, at the very end (plan_fold_prefixes): parked in LDS in one
     // mask until then.  A '\n' is a terminator and a ' ' is line content, which tells them apart again.
@@ -1324,7 +1326,7 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
         rs_store(rf, offsets, rec_lo, R, N, t, rs);
     }
     __syncthreads();
-    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs.w[tid], rs.w[tid + 1]);
+    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs.w);
     Plan pl = plan_passthrough(L.c, L.d.V);
     // the copy and token planes go to the plan, so that k_emit need not classify the bytes again
     if (L.nvalid > 0) { const PlanCT ct = {pl.C, pl.TOK}; plan.ct[t * (u64)TILE_BLOCKS + tid] = ct; }
