@@ -821,10 +821,13 @@ struct SeedTile {
 };
 struct SeedWave {
     SeedTile tile[SEED_TPW];
+    // the folds so far (uniform values: kept here, not in registers, of which the classifier needs every one)
+    J P[SEED_TPW];
+    S X[SEED_TPW];
 };
 
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, u64 nT,
                                               u32 force_open, J* __restrict__ seedJ, S* __restrict__ seedS,
                                               u32* __restrict__ open_count) {
@@ -837,18 +840,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void k_
     const u64 t0 = ((u64)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * SEED_TPW;
     if (t0 >= nT) return;   // whole waves; no workgroup barrier below
     const UniTables ut = lds_tables(uni);
-    J P[SEED_TPW];
-    S X[SEED_TPW];
-    bool back_ok[SEED_TPW], ahead_ok[SEED_TPW];
+    u32 open_mask = 0;   // bit 2k: the back window of tile k is still open, bit 2k+1: its ahead window
 #pragma unroll
     for (int k = 0; k < SEED_TPW; k++) {
-        P[k] = j_identity();
-        X[k] = s_identity();
         const u64 t = t0 + k;
-        back_ok[k] = t == 0 || t >= nT;
+        if (!(t == 0 || t >= nT)) open_mask |= 1u << (2 * k);
         // normalize mode has no lines: nothing of what follows the tile matters to it
-        ahead_ok[k] = NORMALIZE || (t + 1) * TILE_BLOCKS >= nB;   // also t >= nT
+        if (!(NORMALIZE || (t + 1) * TILE_BLOCKS >= nB)) open_mask |= 2u << (2 * k);   // closed also for t >= nT
     }
+    if (lane < SEED_TPW) { sw.P[lane] = j_identity(); sw.X[lane] = s_identity(); }
     // this lane's place: tile k, window block li of the back or of the ahead window
     const int my_k = lane / SEED_LPT, l16 = lane % SEED_LPT;
     const bool is_back = l16 < SEED_BACK;
@@ -859,15 +859,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void k_
     const int rg_k = lane / SEED_RG_LANES, rg_sub = lane % SEED_RG_LANES;
 #pragma unroll 1
     for (int round = 0; round < SEED_ROUNDS; round++) {
-        bool any_open = false;
-        u32 open_mask = 0;   // bit 2k: back window of tile k is open, bit 2k+1: ahead window
-#pragma unroll
-        for (int k = 0; k < SEED_TPW; k++) {
-            if (!back_ok[k]) open_mask |= 1u << (2 * k);
-            if (!ahead_ok[k]) open_mask |= 2u << (2 * k);
-        }
-        any_open = open_mask != 0;
-        if (!any_open) break;
+        if (open_mask == 0) break;
         // ---- stage the open windows: bytes (16-byte chunks, all lanes) ...
         constexpr int CH_BACK = (SEED_BACK + 2) * 4, CH_TILE = CH_BACK + (SEED_AHEAD + 2) * 4;
         for (int c = lane; c < SEED_TPW * CH_TILE; c += 64) {
@@ -945,32 +937,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void k_
             j = lane_J(c, d);
         }
         const WaveLines W = wave_lines(j);
+        u32 still_open = 0;
 #pragma unroll
         for (int k = 0; k < SEED_TPW; k++) {
             const long long tb0 = (long long)((t0 + k) * TILE_BLOCKS);
-            if (!back_ok[k]) {
-                P[k] = j_combine(wave_range_total(W, k * SEED_LPT, k * SEED_LPT + SEED_BACK), P[k]);
-                const bool settled = NORMALIZE ? (P[k].g & (G_RS | G_AH)) != 0
-                                               : (P[k].g & G_RS) != 0 || ((P[k].g & G_LS) && (P[k].g & G_C0));
-                back_ok[k] = settled || tb0 - (long long)SEED_BACK * (round + 1) <= 0;   // or the corpus starts here
+            if ((open_mask >> (2 * k)) & 1u) {
+                J p = wave_range_total(W, k * SEED_LPT, k * SEED_LPT + SEED_BACK);
+                if (round > 0) p = j_combine(p, uniform_J(sw.P[k]));
+                if (lane == 0) sw.P[k] = p;
+                const bool settled = NORMALIZE ? (p.g & (G_RS | G_AH)) != 0
+                                               : (p.g & G_RS) != 0 || ((p.g & G_LS) && (p.g & G_C0));
+                if (!(settled || tb0 - (long long)SEED_BACK * (round + 1) <= 0))   // or the corpus starts here
+                    still_open |= 1u << (2 * k);
             }
-            if (!ahead_ok[k]) {
-                X[k] = s_combine(X[k], s_from_J(wave_range_total(W, k * SEED_LPT + SEED_BACK, (k + 1) * SEED_LPT)));
-                ahead_ok[k] = X[k].has_ls != 0 ||
-                              (u64)(tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * (round + 1)) >= nB;
+            if ((open_mask >> (2 * k + 1)) & 1u) {
+                S x = s_from_J(wave_range_total(W, k * SEED_LPT + SEED_BACK, (k + 1) * SEED_LPT));
+                if (round > 0) x = s_combine(uniform_S(sw.X[k]), x);
+                if (lane == 0) sw.X[k] = x;
+                if (!(x.has_ls != 0 || (u64)(tb0 + TILE_BLOCKS + (long long)SEED_AHEAD * (round + 1)) >= nB))
+                    still_open |= 2u << (2 * k);
             }
         }
-        wave_lds_sync();   // every lane has read the images before the next round overwrites them
+        open_mask = still_open;
+        wave_lds_sync();   // every lane has read the images before the next round overwrites them; the folds are stored
     }
-    bool open = force_open != 0;
-#pragma unroll
-    for (int k = 0; k < SEED_TPW; k++) {
-        if (t0 + k < nT) {
-            if (lane == 0) { seedJ[t0 + k] = P[k]; seedS[t0 + k] = X[k]; }
-            open = open || !(back_ok[k] && ahead_ok[k]);
-        }
+    wave_lds_sync();
+    if (lane < SEED_TPW && t0 + lane < nT) {
+        seedJ[t0 + lane] = sw.P[lane];
+        seedS[t0 + lane] = sw.X[lane];
     }
-    if (open && lane == 0) *open_count = 1u;   // same value from every writer
+    if ((open_mask != 0 || force_open != 0) && lane == 0) *open_count = 1u;   // same value from every writer
 }
 
 // k_tile_carry: what enters tile t from the left (fold of the summaries back to the start of the
