@@ -614,6 +614,18 @@ struct WaveNeighbours {
     __device__ u32 swap_spill(u32 v) const { return from_prev_lane(v); }
 };
 
+// Lanes that hold consecutive blocks in groups (the windows of k_seed): the caller says whether the lanes next
+// to this one belong to its group.
+struct WindowNeighbours {
+    bool next_in_group, prev_in_group;
+    __device__ bool any(bool x) const { return __ballot(x) != 0; }
+    __device__ bool has_next() const { return next_in_group; }
+    __device__ bool has_prev() const { return prev_in_group; }
+    template <class B>
+    __device__ u32 next_planes3(u32 mine, const B&) const { return from_next_lane(mine); }
+    __device__ u32 swap_spill(u32 v) const { return from_prev_lane(v); }
+};
+
 struct LaneCtx {
     Cls c;
     Derived d;
@@ -912,23 +924,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void k_
         const long long wb = first + li;
         const bool live = wb >= 0 && (u64)wb < nB && ((open_mask >> (2 * my_k + (is_back ? 0 : 1))) & 1u);
         J j = j_identity();
+        const SeedTile& st = sw.tile[my_k];
+        const PadBlk blk = {(is_back ? st.back : st.ahead) + (li + 1) * PAD_STRIDE};
+        const u64 q = live ? (u64)wb * 64 : N;
+        const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
+        Cls c;
+        if (!NORMALIZE) {
+            // every lane classifies (a lane without a live block sees no valid byte): the lanes of a window
+            // hold consecutive blocks and pass what runs over a block edge to each other
+            WindowNeighbours nb = {l16 != SEED_BACK - 1 && l16 != SEED_LPT - 1, l16 != 0 && l16 != SEED_BACK};
+            c = classify_block_fast(blk, nvalid, ut, nb);
+        }
         if (live) {
-            const u64 q = (u64)wb * 64;
-            const SeedTile& st = sw.tile[my_k];
-            const PadBlk blk = {(is_back ? st.back : st.ahead) + (li + 1) * PAD_STRIDE};
             const u64* rsw = is_back ? st.rs_back : st.rs_ahead;
-            const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
             const u64 V = below(nvalid);
             const u64 RS = rsw[li] & V;
             const bool nrs = (rsw[li + 1] & 1ull) != 0;
-            Cls c;
             Derived d;
             if (NORMALIZE) {
                 Cls z = {classify_ws_fast(blk, nvalid), 0, 0, 0, 0, 0, 0};
                 c = normalize_cls(z, V);
                 d = derive(c, V, RS, false, false);
             } else {
-                c = classify_block_fast(blk, nvalid, ut);
                 const bool has_next = q + 64 < N;
                 const bool next_nl = has_next && blk[64] == '\n' && !nrs;
                 const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
