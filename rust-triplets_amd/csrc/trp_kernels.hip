@@ -686,25 +686,43 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
 // ---------------------------------------------------------------------------------------------------
 // rec_lo_w: the same for sub-tiles (w = 0..nW, and rec_lo_w[nW+1] for N).
 // The first kernel of a batch: it also clears the batch's totals and counters (totals[0..15]).
-__global__ void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW, u32* __restrict__ rec_lo,
-                         u32* __restrict__ rec_lo_w, u64* __restrict__ totals) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 16) totals[i] = 0;
-    u64 key;
-    u32* dst;
-    if (i <= nT + 1) { key = i <= nT ? i * (u64)TILE : N; dst = rec_lo + i; }
-    else {
-        i -= nT + 2;
-        if (i > nW + 1) return;
-        key = i <= nW ? i * (u64)SUB : N;
-        dst = rec_lo_w + i;
+// One thread per gap between consecutive record starts: thread r (0..R) owns the keys in (offsets[r-1], offsets[r]]
+// (everything up to offsets[0] for r = 0, everything above offsets[R-1] for r = R) and writes r, the number of
+// record starts below such a key, to the entries whose key falls there.  Most gaps hold a few entries; a long
+// one (a record of many tiles) is written by the whole wavefront.  Entries are clamped to the arrays, whatever
+// the offsets hold.
+__device__ inline void rec_lo_fill(u32* __restrict__ dst, u64 unit, u64 n_units, u64 N, bool has_lo, u64 lo, bool has_hi,
+                                   u64 hi, u32 r) {
+    // entries i in [first, last]: lo < i * unit <= hi; entry n_units + 1 belongs to the key N
+    u64 first = has_lo ? lo / unit + 1 : 0;
+    u64 last = has_hi ? hi / unit : n_units;
+    if (last > n_units) last = n_units;
+    if ((!has_lo || lo < N) && (!has_hi || N <= hi)) dst[n_units + 1] = r;
+    constexpr u64 OWN = 8;
+    const u64 count = first <= last ? last - first + 1 : 0;
+    for (u64 i = 0; i < (count < OWN ? count : OWN); i++) dst[first + i] = r;
+    u64 wide = __ballot(count > OWN);
+    const int lane = threadIdx.x & 63;
+    while (wide) {   // uniform
+        const int l = ctz(wide);
+        wide &= wide - 1;
+        const u64 f = ((u64)readlane_u32((u32)(first >> 32), l) << 32) | readlane_u32((u32)first, l);
+        const u64 e = ((u64)readlane_u32((u32)(last >> 32), l) << 32) | readlane_u32((u32)last, l);
+        const u32 v = readlane_u32(r, l);
+        for (u64 i = f + OWN + (u64)lane; i <= e; i += 64) dst[i] = v;
     }
-    u64 lo = 0, hi = R;
-    while (lo < hi) {
-        u64 mid = (lo + hi) >> 1;
-        if (offsets[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    *dst = (u32)lo;
+}
+__global__ __launch_bounds__(256) void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW,
+                                                u32* __restrict__ rec_lo, u32* __restrict__ rec_lo_w,
+                                                u64* __restrict__ totals) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < 16) totals[r] = 0;
+    const bool live = r <= R;   // whole wavefronts stay: the long gaps are written together
+    const bool has_lo = live && r > 0, has_hi = live && r < R;
+    const u64 lo = has_lo ? offsets[r - 1] : 0, hi = has_hi ? offsets[r] : 0;
+    // a thread beyond R owns nothing: an empty gap
+    rec_lo_fill(rec_lo, TILE, nT, N, live ? has_lo : true, live ? lo : ~0ull, live ? has_hi : true, live ? hi : 0, (u32)r);
+    rec_lo_fill(rec_lo_w, SUB, nW, N, live ? has_lo : true, live ? lo : ~0ull, live ? has_hi : true, live ? hi : 0, (u32)r);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2646,7 +2664,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
     J* SA = B.SA;
     {
         Prof pr(c, "k_rec_lo");   // also clears the totals and counters
-        hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((nT + nW + 4 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, nW, rec_lo,
+        hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, nW, rec_lo,
                            B.rec_lo_w, totals);
     }
     if (nT) {
