@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
 // ---------------------------------------------------------------------------------------------------
 // generic exclusive scan of u64 (3 kernels), out has n+1 entries
 // ---------------------------------------------------------------------------------------------------
-constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_ITEMS = 2;    // small chunks: these kernels are short and latency-bound, more workgroups finish sooner
 constexpr int SCAN_CHUNK = NT * SCAN_ITEMS;
 
 __global__ __launch_bounds__(NT) void k_scan_reduce(const u64* __restrict__ in, u64 n, u64* __restrict__ partial) {
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(NT) void k_scan_final(const u64* __restrict__ in, u
 // The two scans of the path in two kernels each.  k_scan_reduce_gen computes the values to be scanned with a
 // generator (which also stores them for the second kernel) and reduces them per workgroup; k_scan_final_sum
 // adds up the partial sums before its own workgroup itself instead of waiting for a single-workgroup scan of
-// them in between (a few loads per thread: there are n / 2048 partial sums; beyond SCAN_SUM_MAX of them the
+// them in between (a few loads per thread: there are n / SCAN_CHUNK partial sums; beyond SCAN_SUM_MAX of them the
 // three-kernel form is used).  Letting the last workgroup of the first kernel scan the partial sums instead was
 // measured slower: the device-wide fence it needs writes back every workgroup's L2 lines.
 //
@@ -2329,7 +2329,7 @@ constexpr ScratchLayout scratch_layout() {
     constexpr size_t nT = (NOALLOC_MAX_BYTES + TILE - 1) / TILE, nB = (NOALLOC_MAX_BYTES + BLOCK - 1) / BLOCK;
     constexpr size_t nW = (NOALLOC_MAX_BYTES + SUB - 1) / SUB;
     constexpr size_t R = NOALLOC_MAX_RECORDS;
-    constexpr size_t nPart = ((nW > R ? nW : R) + NT * 8 - 1) / (NT * 8) + 1;
+    constexpr size_t nPart = ((nW > R ? nW : R) + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
     ScratchLayout L = {};
     size_t at = 0;
     L.totals = at;     at = align256(at + 16 * sizeof(u64));
