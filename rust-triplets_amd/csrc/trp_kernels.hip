@@ -1342,8 +1342,6 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
                                                       u64 nB, PlanMem plan, u32* __restrict__ tile_bytes,
                                                       u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
     __shared__ TileShared sh;
-    __shared__ UniShared uni;
-    __shared__ u64 tokc[TILE_BLOCKS];
     __shared__ RsShared rs;
     const int tid = threadIdx.x, lane = tid & 63;
     const u64 t = blockIdx.x, tS = t * (u64)TILE;
@@ -1352,30 +1350,33 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
         RsFetch rf;
         tile_load(bytes, N, tS, regs);
         rs_fetch(offsets, rec_lo, R, t, rf);
-        stage_tables(uni);
         tile_store(regs, sh.bytes);
         rs_store(rf, offsets, rec_lo, R, N, t, rs);
     }
     __syncthreads();
-    LaneCtx L = lane_setup(sh, lds_tables(uni), N, tS, false, rs.w);
+    const UniTables no_tables = {nullptr, nullptr, 0, nullptr};   // the whitespace classifier uses none
+    LaneCtx L = lane_setup(sh, no_tables, N, tS, false, rs.w);
     Plan pl = plan_passthrough(L.c, L.d.V);
     // the copy and token planes go to the plan, so that k_emit need not classify the bytes again
     if (L.nvalid > 0) { const PlanCT ct = {pl.C, pl.TOK}; plan.ct[t * (u64)TILE_BLOCKS + tid] = ct; }
-    tokc[tid] = pl.TOK;
-    __syncthreads();
-    bool prev_tok = (lane & (SUB_BLOCKS - 1)) > 0 && (tokc[tid - 1] >> 63);   // counts per sub-tile, as in k_plan
+    // counts per sub-tile (half a wavefront), as in k_plan: one row-wise DPP sum, lanes 31 and 63 hold the totals
+    const u32 left_tok = from_prev_lane((u32)(pl.TOK >> 63));
+    const bool prev_tok = (lane & (SUB_BLOCKS - 1)) > 0 && left_tok != 0;
     u32 ntk = popc(token_starts(pl.TOK, L.d.RS, prev_tok));
-    const bool last_tok = __shfl((int)(u32)(pl.TOK >> 63), lane | (SUB_BLOCKS - 1), 64) != 0;
-#pragma unroll
-    for (int off = SUB_BLOCKS / 2; off > 0; off >>= 1) ntk += __shfl_down((int)ntk, off, SUB_BLOCKS);
-    if ((lane & (SUB_BLOCKS - 1)) == 0) {
+    ntk += (u32)__builtin_amdgcn_update_dpp(0, (int)ntk, 0x111, 0xf, 0xf, false);   // row_shr:1
+    ntk += (u32)__builtin_amdgcn_update_dpp(0, (int)ntk, 0x112, 0xf, 0xf, false);   // row_shr:2
+    ntk += (u32)__builtin_amdgcn_update_dpp(0, (int)ntk, 0x114, 0xf, 0xf, false);   // row_shr:4
+    ntk += (u32)__builtin_amdgcn_update_dpp(0, (int)ntk, 0x118, 0xf, 0xf, false);   // row_shr:8
+    ntk += (u32)__builtin_amdgcn_update_dpp(0, (int)ntk, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    const u64 first_cont = __ballot((pl.TOK & 1ull) && !(L.d.RS & 1ull));   // bits 0 and 32: the halves' first blocks
+    if ((lane & (SUB_BLOCKS - 1)) == SUB_BLOCKS - 1) {
         const u64 sub = (t * (u64)TILE_BLOCKS + tid) / SUB_BLOCKS, sS = sub * (u64)SUB;
         if (sS < N) {
             tile_bytes[sub] = (u32)(N - sS < (u64)SUB ? N - sS : (u64)SUB);
             tile_toks[sub] = ntk;
             u32 f = 0;
-            if ((pl.TOK & 1ull) && !(L.d.RS & 1ull)) f |= TF_FIRST_CONT;
-            if (last_tok) f |= TF_LAST_TOK;
+            if ((first_cont >> (lane - (SUB_BLOCKS - 1))) & 1ull) f |= TF_FIRST_CONT;
+            if (pl.TOK >> 63) f |= TF_LAST_TOK;
             tile_flags[sub] = f;
         }
     }
