@@ -157,7 +157,11 @@ void trp_trim_host_pool(void);
  * (the totals in `out` are read back).  The kernels run on the context's stream (trp_stream): inputs
  * produced on another stream must be ordered before the call, either by creating the context on the
  * producer's stream (trp_create_on_stream) or with an event (trp_wait_event); a context made by
- * trp_create runs on a private non-blocking stream that waits for nothing by itself. */
+ * trp_create runs on a private non-blocking stream that waits for nothing by itself.
+ * The offsets (same contract as above, with offsets[n_records] = n_bytes) are checked by the first kernel, as
+ * the host cannot see them: a batch whose offsets break the contract fails with TRP_E_ARG once its kernels
+ * have run (its result arrays hold nothing of use); no kernel reads or writes outside its arrays because of
+ * them. */
 int trp_preprocess_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                 uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
                                 trp_result* out);

@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -543,6 +544,17 @@ __device__ inline PadBlk lane_block(const TileShared& sh, int i) {
 struct RsShared {
     u64 w[TILE_BLOCKS + 1];
 };
+// Two consecutive entries of rec_lo / rec_lo_w as a range of records.  With offsets that are not
+// non-decreasing (invalid input) k_rec_lo leaves entries unwritten or out of order: whatever they hold, the range
+// stays inside [0, R] and is never negative, so that no loop over it runs away.
+struct RecRange { u32 r0, r1; };
+__device__ inline RecRange rec_range(const u32* __restrict__ lo, u64 i, u64 R) {
+    u32 r0 = lo[i], r1 = lo[i + 1];
+    if (r1 > (u32)R) r1 = (u32)R;
+    if (r0 > r1) r0 = r1;
+    RecRange g = {r0, r1};
+    return g;
+}
 struct RsFetch {
     u32 q;   // wave 0: start offset of record r0 + lane, r1 included (or ~0; a batch is shorter than 4 GiB)
     u32 n;   // wave 0: r1 - r0
@@ -553,7 +565,8 @@ __device__ inline u32 rs_fetch(const u64* __restrict__ offsets, const u32* __res
     f.q = ~0u;
     f.n = 0;
     if (threadIdx.x >= 64) return 0;
-    const u32 r0 = rec_lo[t], r1 = rec_lo[t + 1];
+    const RecRange g = rec_range(rec_lo, t, R);
+    const u32 r0 = g.r0, r1 = g.r1;
     const u64 r = (u64)r0 + threadIdx.x;
     f.n = r1 - r0;
     if (r <= r1 && r < R) f.q = (u32)offsets[r];
@@ -571,7 +584,7 @@ __device__ inline void rs_store(const RsFetch& f, const u64* __restrict__ offset
     for (int i = threadIdx.x; i <= TILE_BLOCKS; i += 64) rs.w[i] = 0;
     if (f.q != ~0u) rs_set(rs, f.q, N, tS);
     if (f.n >= 64) {   // crowded tile: the rest of its records
-        const u64 r0 = rec_lo[t], r1 = (u64)r0 + f.n;
+        const u64 r0 = rec_range(rec_lo, t, R).r0, r1 = (u64)r0 + f.n;
         for (u64 r = r0 + 64 + threadIdx.x; r <= r1 && r < R; r += 64) rs_set(rs, offsets[r], N, tS);
     }
 }
@@ -582,7 +595,8 @@ __device__ inline void rs_store(const RsFetch& f, const u64* __restrict__ offset
 __device__ inline u64 block_record_starts(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
                                           u64 N, u64 wb, bool* next) {
     const u64 lo = wb * 64;
-    u64 a = rec_lo[wb / TILE_BLOCKS], b = rec_lo[wb / TILE_BLOCKS + 1];   // the block's tile narrows the search
+    const RecRange g = rec_range(rec_lo, wb / TILE_BLOCKS, R);   // the block's tile narrows the search
+    u64 a = g.r0, b = g.r1;
     while (a < b) {
         const u64 m = (a + b) >> 1;
         if (offsets[m] < lo) a = m + 1; else b = m;
@@ -712,14 +726,17 @@ __device__ inline void rec_lo_fill(u32* __restrict__ dst, u64 unit, u64 n_units,
         for (u64 i = f + OWN + (u64)lane; i <= e; i += 64) dst[i] = v;
     }
 }
+// The offsets are checked on the way (offsets[0] = 0, non-decreasing, offsets[R] = N): a thread that finds them
+// wrong writes the batch's number `seq` to totals[9], which is never cleared - an older number means nothing.
 __global__ __launch_bounds__(256) void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW,
                                                 u32* __restrict__ rec_lo, u32* __restrict__ rec_lo_w,
-                                                u64* __restrict__ totals) {
+                                                u64* __restrict__ totals, u64 seq) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < 16) totals[r] = 0;
+    if (r < 16 && r != 9) totals[r] = 0;
     const bool live = r <= R;   // whole wavefronts stay: the long gaps are written together
     const bool has_lo = live && r > 0, has_hi = live && r < R;
     const u64 lo = has_lo ? offsets[r - 1] : 0, hi = has_hi ? offsets[r] : 0;
+    if ((has_lo && has_hi && lo > hi) || (r == 0 && offsets[0] != 0) || (r == R && offsets[R] != N)) totals[9] = seq;
     // a thread beyond R owns nothing: an empty gap
     rec_lo_fill(rec_lo, TILE, nT, N, live ? has_lo : true, live ? lo : ~0ull, live ? has_hi : true, live ? hi : 0, (u32)r);
     rec_lo_fill(rec_lo_w, SUB, nW, N, live ? has_lo : true, live ? lo : ~0ull, live ? has_hi : true, live ? hi : 0, (u32)r);
@@ -922,7 +939,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 const long long lo_blk = first < 0 ? 0 : first, hi_blk = first + n;   // starts in [lo_blk*64, (hi_blk+1)*64)
                 if (hi_blk >= 0) {
                     const u64 T0 = (u64)lo_blk / TILE_BLOCKS, T1 = (u64)hi_blk / TILE_BLOCKS;
-                    const u64 r0 = rec_lo[T0 < nT ? T0 : nT], r1 = rec_lo[T1 + 1 < nT ? T1 + 1 : nT];
+                    u64 r0 = rec_lo[T0 < nT ? T0 : nT], r1 = rec_lo[T1 + 1 < nT ? T1 + 1 : nT];
+                    if (r1 > R) r1 = R;   // (entries left behind by invalid offsets)
+                    if (r0 > r1) r0 = r1;
                     const u64 w0 = (u64)lo_blk * 64, w1 = ((u64)hi_blk + 1) * 64;
                     u64* rs = bk ? sw.tile[k].rs_back : sw.tile[k].rs_ahead;
                     for (u64 r = r0 + rg_sub; r < r1; r += SEED_RG_LANES) {
@@ -1744,7 +1763,8 @@ __device__ inline void sub_store(const SubRegs& r, u8* sb) {
 // Record starts of sub-tile s: records [rec_lo_w[s], rec_lo_w[s+1]) start inside it (see rs_fetch / rs_store).
 __device__ inline u32 sub_rs_fetch(const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 s,
                                    RsFetch& f) {
-    const u32 r0 = rec_lo_w[s], r1 = rec_lo_w[s + 1];
+    const RecRange g = rec_range(rec_lo_w, s, R);
+    const u32 r0 = g.r0, r1 = g.r1;
     const u64 r = (u64)r0 + threadIdx.x;
     f.q = ~0u;
     f.n = r1 - r0;
@@ -1761,7 +1781,7 @@ __device__ inline void sub_rs_store(const RsFetch& f, const u64* __restrict__ of
     for (int i = threadIdx.x; i <= 64; i += 64) rs.w[i] = 0;
     if (f.q != ~0u) sub_rs_set(rs, f.q, N, sS);
     if (f.n >= 64) {   // crowded sub-tile: the rest of its records
-        const u64 r0 = rec_lo_w[s], r1 = (u64)r0 + f.n;
+        const u64 r0 = rec_range(rec_lo_w, s, R).r0, r1 = (u64)r0 + f.n;
         for (u64 r = r0 + 64 + threadIdx.x; r <= r1 && r < R; r += 64) sub_rs_set(rs, offsets[r], N, sS);
     }
 }
@@ -2089,7 +2109,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
 // One lane per record (wavefronts stride over the records): a record's first CHUNK_INLINE descriptors are
 // written by its lane, the rest of a record with many windows by the whole wavefront.
 constexpr u32 CHUNK_INLINE = 4;
-// The last kernel of a batch: its first thread also copies the batch's totals and flags (totals[0..8]) into the
+// The last kernel of a batch: its first thread also copies the batch's totals and flags (totals[0..9]) into the
 // page-locked host words `host_totals`, which spares a copy command behind the kernels.
 __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off, u64 R, DevCfg cfg,
                              u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals,
@@ -2099,7 +2119,7 @@ __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __res
         totals[2] = C;
         totals[3] = C > capacity ? 1 : 0;
         if (host_totals) {
-            for (int i = 0; i < 9; i++) host_totals[i] = i == 2 ? C : i == 3 ? (u64)(C > capacity ? 1 : 0) : totals[i];
+            for (int i = 0; i < 10; i++) host_totals[i] = i == 2 ? C : i == 3 ? (u64)(C > capacity ? 1 : 0) : totals[i];
             __threadfence_system();
         }
     }
@@ -2375,6 +2395,10 @@ static int scratch_of_device(int device, unsigned char** out) {
     return TRP_OK;
 }
 
+// Numbers the batches of the whole process (PathBufs::seq): contexts on one GPU share the fixed scratch array,
+// so a number must never come back on another context.
+static std::atomic<u64> g_batch_seq{0};
+
 struct trp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -2410,6 +2434,7 @@ struct trp_ctx {
         const uint64_t* d_offsets = nullptr;
         u64 R = 0, N = 0, nT = 0, g3_cap = 0, chunk_cap = 0;
         bool with_summary = false;
+        u64 seq = 0;
         DevCfg dc = {};
     } pending;
     // Profiling aid: with profiling on and TRP_PROFILE_EMIT_STOP=k (1..5) in the environment, k_emit ends
@@ -2551,6 +2576,7 @@ static int create_ctx(int device, hipStream_t stream, bool own, trp_ctx** out) {
         if (e != hipSuccess) { delete c; return fail(TRP_E_HIP, "hipStreamCreate failed"); }
     }
     e = hipHostMalloc((void**)&c->h_totals, 16 * sizeof(u64), hipHostMallocDefault);
+    if (e == hipSuccess) memset(c->h_totals, 0, 16 * sizeof(u64));
     if (e != hipSuccess) {
         if (own) (void)hipStreamDestroy(c->stream);
         delete c;
@@ -2642,6 +2668,7 @@ struct PathBufs {
     u8* dropped;
     u32 *tok_start, *tok_len;
     ChunkDesc* chunks; u64 chunk_cap;
+    u64 seq = 0;   // number of the batch (never 0): how k_rec_lo reports offsets that are not what the header asks for
 };
 
 // Token table entries a batch can need.  A token needs one byte, and two tokens of one record a separator byte
@@ -2666,7 +2693,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
     {
         Prof pr(c, "k_rec_lo");   // also clears the totals and counters
         hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, nW, rec_lo,
-                           B.rec_lo_w, totals);
+                           B.rec_lo_w, totals, B.seq);
     }
     if (nT) {
         if (!pass) {
@@ -2782,7 +2809,10 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     if ((rc = c->tok_start.ensure(tok_cap * sizeof(u32)))) return rc;
     if ((rc = c->tok_len.ensure(tok_cap * sizeof(u32)))) return rc;
     if ((rc = c->chunks.ensure(chunk_cap * sizeof(ChunkDesc)))) return rc;
-    if ((rc = c->totals.ensure(16 * sizeof(u64)))) return rc;
+    if (!c->totals.p) {
+        if ((rc = c->totals.ensure(16 * sizeof(u64)))) return rc;
+        HIPCHK(hipMemsetAsync(c->totals.p, 0, 16 * sizeof(u64), c->stream));   // totals[9] is compared, never cleared
+    }
     if ((rc = c->plan.ensure(plan_bytes(nB)))) return rc;
     if (!pass) {
         if ((rc = c->SA.ensure((nT + 1) * sizeof(J)))) return rc;
@@ -2809,6 +2839,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     B.dropped = c->dropped.as<u8>();
     B.tok_start = c->tok_start.as<u32>(); B.tok_len = c->tok_len.as<u32>();
     B.chunks = c->chunks.as<ChunkDesc>(); B.chunk_cap = chunk_cap;
+    B.seq = ++g_batch_seq;
     drop_events(c);
     const bool with_summary = c->summary_path;
     if ((rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc, with_summary))) return rc;
@@ -2821,6 +2852,7 @@ static int submit_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_o
     c->pending.g3_cap = g3_cap;
     c->pending.chunk_cap = chunk_cap;
     c->pending.with_summary = with_summary;
+    c->pending.seq = B.seq;
     c->pending.dc = dc;
     return TRP_OK;
 }
@@ -2840,6 +2872,8 @@ static int collect_device(trp_ctx* c, trp_result* out) {
     u64* totals = c->totals.as<u64>();
     u64 *den_off = c->den_off.as<u64>(), *tok_off = c->tok_off.as<u64>(), *chunk_off = c->chunk_off.as<u64>();
     HIPCHK(hipStreamSynchronize(st));
+    if (c->h_totals[9] == pd.seq)
+        return fail(TRP_E_ARG, "offsets must start at 0, be non-decreasing and end at n_bytes");
     if (!pass && nT) {
         const bool open = (u32)c->h_totals[8] != 0;   // k_seed left tiles open (or the test switch forces the path)
         if (open && !pd.with_summary) {
@@ -2954,10 +2988,12 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
     c->profiling = false;
     for (int attempt = 0; attempt < 2; attempt++) {
         const bool with_summary = c->summary_path;
+        B.seq = ++g_batch_seq;
         rc = enqueue_path(c, c->stream, B, d_bytes, d_offsets, R, N, dc, with_summary);   // starts by clearing the totals and counters
         if (rc) break;
         hipError_t e = hipStreamSynchronize(c->stream);   // the last kernel has written the totals into pinned memory
         if (e != hipSuccess) { rc = fail(TRP_E_HIP, std::string("noalloc batch: ") + hipGetErrorString(e)); break; }
+        if (c->h_totals[9] == B.seq) { rc = fail(TRP_E_ARG, "offsets must start at 0, be non-decreasing and end at n_bytes"); break; }
         const bool open = !pass && N && (u32)c->h_totals[8] != 0;
         if (open && !with_summary) { c->summary_path = true; continue; }   // once more, with the summary kernels
         if (!pass && N && !open && !c->force_summary) c->summary_path = false;

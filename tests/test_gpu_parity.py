@@ -430,3 +430,34 @@ def test_inputs_produced_on_the_callers_stream_need_no_sync(T):
         on_torch.close()
         on_side.close()
         private.close()
+
+
+def test_device_entry_point_rejects_offsets_that_break_the_contract(T, ctx):
+    """The device entry point cannot look at the offsets on the host: the first kernel checks them (start at 0,
+    non-decreasing, end at n_bytes) and the call fails with an argument error instead of running away; the context
+    is usable afterwards, with and without the denoiser."""
+    import torch
+    recs = textgen.corpus(77, 400)
+    data, offs = O.pack(recs)
+    R, N = len(recs), len(data)
+    db = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).cuda()
+    good = offs.astype(np.int64)
+    bad_sets = []
+    a = good.copy(); a[R // 2], a[R // 2 + 1] = good[R // 2 + 1], good[R // 2]; bad_sets.append(a)     # one pair swapped
+    a = good.copy(); a[0] = 1; bad_sets.append(a)                                                        # does not start at 0
+    a = good.copy(); a[R] = N - 1; bad_sets.append(a)                                                    # does not end at N
+    a = good[::-1].copy(); bad_sets.append(a)                                                            # decreasing throughout
+    den_on, den_off = T.DenoiserConfig(True, 0.35, True), T.DenoiserConfig(False, 0.35, True)
+    st = T.ChunkingStrategy(max_window_tokens=16, overlap_tokens=[3], summary_fallback_tokens=4)
+    torch.cuda.synchronize()
+    for den in (den_on, den_off):
+        for bad in bad_sets:
+            do = torch.from_numpy(bad).cuda()
+            torch.cuda.synchronize()
+            with pytest.raises(T.TripletsAmdError):
+                ctx.preprocess_batch_device(db.data_ptr(), do.data_ptr(), R, N, den, st)
+        do = torch.from_numpy(good).cuda()
+        torch.cuda.synchronize()
+        got = ctx.preprocess_batch_device(db.data_ptr(), do.data_ptr(), R, N, den, st).to_host()
+        exp = O.batch(data, offs, O.make_config(den.enabled, 0.35, True, 16, (3,), 4))
+        assert_same(exp, got, recs, "after rejected batches, denoiser %s" % den.enabled)
