@@ -1157,8 +1157,6 @@ __host__ __device__ inline PlanMem plan_view(void* base, u64 nB) {
 struct PlanShared {
     TileShared tile;   // byte image; after classification reused for the eight G3Masks arrays
     J jscan[NT / 64];
-    J seed_j;
-    S seed_s;
     u64 tokc[TILE_BLOCKS];
     u64 marks[TILE_BLOCKS];
     uint16_t list[G3_LCAP];
@@ -1192,8 +1190,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         tile_store(regs, sh.tile.bytes);
         rs_store(rf, offsets, rec_lo, R, N, t, sh.rs);
     }
-    if (tid == 0) sh.seed_j = seedJ[t];
-    if (tid == 64) sh.seed_s = seedS[t];
+    // what enters the tile from its neighbours: the same address for every lane, loaded into scalar registers
+    const J seed_j = seedJ[t];
+    const S seed_s = seedS[t];
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
     LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w, NORMALIZE);
@@ -1222,8 +1221,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     __syncthreads();   // also: every lane has classified its block, the byte image is free from here on
     // what enters this wave from the left and from the right: folds over the other waves' totals.  The
     // summaries are the same for every lane: moved to scalar registers, so that the folds run on the scalar unit
-    J Pw = uniform_J(sh.seed_j);
-    S Xw = uniform_S(sh.seed_s);
+    J Pw = uniform_J(seed_j);
+    S Xw = uniform_S(seed_s);
     {
         const int wu = __builtin_amdgcn_readfirstlane(wave);   // scalar: the branches below are uniform
 #pragma unroll
