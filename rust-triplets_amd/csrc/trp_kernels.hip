@@ -7,9 +7,9 @@
 //   SA[nT]                        per-tile forward summary (struct J) written by k_summary (fallback path)
 //   plan: ct[nB] (2 x u64)        emit plan bit planes C and TOK of every block, written by k_plan / k_gate3
 //         px[nB] (2 x u64)        the planes PSP and PNL, only of the blocks that have or may get a separator
-//         pfx_mask[nW]            which blocks of a sub-tile those are (one bit per block)
+//         pfx_mask[nB/64]         which blocks those are (one bit per block)
 //   g3list[]                      digit-heavy lines that k_plan could not solve inside a tile (position | flags)
-//   rec_lo_w[nW+2]               the same per 4 KiB sub-tile (nW = ceil(N/4096)): k_emit works one wavefront per sub-tile
+//   rec_lo_w[nW+2]                the same per 2 KiB sub-tile (nW = ceil(N/2048)): k_emit works one wavefront per sub-tile
 //   tile_bytes[nW], tile_toks[nW], tile_flags[nW]   emitted bytes / token starts per sub-tile
 //   tile_base[nW+1]               exclusive prefix of (bytes | toks<<32)
 //   denoised[D], tok_start[T], tok_len[T], *_offsets[R+1], chunks[C]   results

@@ -294,9 +294,9 @@ def test_one_byte_records_fill_the_token_table(T, ctx):
 
 
 def test_token_density_around_the_staged_table_of_a_sub_tile(T, ctx):
-    """k_emit stages the tokens of a 4 KiB sub-tile in LDS up to a fixed number and stores the rest directly:
+    """k_emit stages the tokens of a 2 KiB sub-tile in LDS up to a fixed number and stores the rest directly:
     token densities below, at and above that number, tokens that straddle every sub-tile edge (word lengths
-    that do not divide 4096), a token longer than several sub-tiles between dense stretches, many records per
+    that do not divide 2048), a token longer than several sub-tiles between dense stretches, many records per
     sub-tile and records that end exactly on sub-tile edges; denoiser on and off, and normalize mode."""
     import test_normalize as TN
     dense = [b"a b " * 5000, b"ab cd " * 4000, b"abc def " * 3000, b"abcd efg " * 2500, b"abcdefg hi " * 2000]
