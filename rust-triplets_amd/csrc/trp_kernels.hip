@@ -1449,6 +1449,190 @@ __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* 
             });
 }
 
+}  // namespace
+
+// ---- gate 3 for long lines: one wavefront per line ---------------------------------------------------
+// The bit vectors of the mask solver spread over the lanes of a wavefront: lane L holds the words
+// L * W .. L * W + W - 1 (W * 4 KiB of text per vector).  The operations g3_bits_solve needs (trp_lane.h):
+// carries, shifted-in bits and the mirror image cross the lanes through ballots, DPP and ds_bpermute.
+namespace trp {
+template <int W>
+struct WaveBits {
+    u64 w[W];
+};
+template <int W>
+__device__ inline WaveBits<W> g3b_and(const WaveBits<W>& a, const WaveBits<W>& b) {
+    WaveBits<W> r;
+#pragma unroll
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] & b.w[j];
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_andn(const WaveBits<W>& a, const WaveBits<W>& b) {
+    WaveBits<W> r;
+#pragma unroll
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] & ~b.w[j];
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_or(const WaveBits<W>& a, const WaveBits<W>& b) {
+    WaveBits<W> r;
+#pragma unroll
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] | b.w[j];
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_orn(const WaveBits<W>& a, const WaveBits<W>& b) {
+    WaveBits<W> r;
+#pragma unroll
+    for (int j = 0; j < W; j++) r.w[j] = a.w[j] | ~b.w[j];
+    return r;
+}
+template <int W>
+__device__ inline bool g3b_any(const WaveBits<W>& a) {
+    u64 x = 0;
+#pragma unroll
+    for (int j = 0; j < W; j++) x |= a.w[j];
+    return __ballot(x != 0) != 0;
+}
+template <int W>
+__device__ inline u32 g3b_popc_and(const WaveBits<W>& a, const WaveBits<W>& b) {
+    u32 n = 0;
+#pragma unroll
+    for (int j = 0; j < W; j++) n += (u32)popc(a.w[j] & b.w[j]);
+    return readlane_u32(wave_incl_scan_add(n), 63);
+}
+// Sum of two vectors.  A lane's own words are added with their carries; g = the lane carries out, p = the
+// lane would pass a carry on (all its sum bits are ones).  The carry into every lane follows from the two
+// ballots like the carries of a binary addition: c[i+1] = g[i] | (p[i] & c[i]).
+template <int W>
+__device__ inline WaveBits<W> g3b_add(const WaveBits<W>& a, const WaveBits<W>& b) {
+    WaveBits<W> r;
+    unsigned long long c = 0;
+    u64 all = ~0ull;
+#pragma unroll
+    for (int j = 0; j < W; j++) { r.w[j] = __builtin_addcll(a.w[j], b.w[j], c, &c); all &= r.w[j]; }
+    const u64 G = __ballot(c != 0), P = __ballot(all == ~0ull);
+    const u64 V = G << 1;
+    const u64 C = V | ((P + V) ^ P ^ V);
+    u64 cin = (C >> (threadIdx.x & 63)) & 1ull;
+#pragma unroll
+    for (int j = 0; j < W; j++) { r.w[j] += cin; cin = (cin && r.w[j] == 0) ? 1ull : 0ull; }
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_run_starts(const WaveBits<W>& x) {
+    WaveBits<W> r;
+    u64 c = from_prev_lane((u32)(x.w[W - 1] >> 63));   // the last bit of the lane before (lane 0: none)
+#pragma unroll
+    for (int j = 0; j < W; j++) { r.w[j] = x.w[j] & ~((x.w[j] << 1) | c); c = x.w[j] >> 63; }
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_run_ends(const WaveBits<W>& x) {
+    WaveBits<W> r;
+    const u64 nl = from_next_lane((u32)(x.w[0] & 1ull));   // the first bit of the lane after (lane 63: none)
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const u64 nx = j + 1 < W ? (x.w[j + 1 < W ? j + 1 : 0] & 1ull) : nl;
+        r.w[j] = x.w[j] & ~((x.w[j] >> 1) | (nx << 63));
+    }
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_run_from(const WaveBits<W>& x, const WaveBits<W>& points) { return g3b_andn(x, g3b_add(x, points)); }
+template <int W>
+__device__ inline WaveBits<W> g3b_rev(const WaveBits<W>& a) {
+    WaveBits<W> r;
+    const int src = 63 - (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const u64 v = a.w[W - 1 - j];
+        const u32 lo = (u32)__shfl((int)(u32)v, src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
+        r.w[j] = bitrev64((u64)lo | ((u64)hi << 32));
+    }
+    return r;
+}
+template <int W>
+__device__ inline void g3b_opaque(WaveBits<W>&) {}
+}  // namespace trp
+
+namespace {
+// One digit-heavy line of up to 64 * W blocks solved by the whole wavefront (every lane takes part): lane L
+// classifies blocks L * W .. L * W + W - 1 of the view that begins with the line's first block, the line's
+// end is the first line start after its first byte, and the solver of the short lines runs on WaveBits.
+// Returns false when the line does not end inside the view.
+template <int W>
+__device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                    const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, const DevCfg& cfg,
+                                    const PlanMem& plan, u64 p, bool table, bool rab, u32* tile_bytes, u32* tile_toks,
+                                    const UniTables& ut) {
+    const int lane = threadIdx.x & 63;
+    const u64 w0 = p >> 6;
+    WaveBits<W> X, DG, AL;
+    u32 my_end = 0xFFFFFFFFu;   // view-relative position of the first line start in this lane's blocks
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const u64 wb = w0 + (u64)(lane * W + j);
+        X.w[j] = DG.w[j] = AL.w[j] = 0;
+        if (wb < nB) {
+            const GuardBlk blk = {bytes, wb * 64, N};
+            const u64 q = wb * 64;
+            const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
+            const Cls c = classify_block_fast(blk, nvalid, ut);
+            const u64 V = below(nvalid);
+            bool nrs;
+            const u64 RS = block_record_starts(offsets, rec_lo, R, N, wb, &nrs) & V;
+            const bool has_next = q + 64 < N;
+            const bool next_nl = has_next && blk[64] == '\n' && !nrs;
+            const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
+            u64 LS = derive(c, V, RS, next_nl, pt).LS;
+            if (lane == 0 && j == 0) LS &= ~below((int)(p & 63) + 1);
+            if (LS && my_end == 0xFFFFFFFFu) my_end = (u32)((lane * W + j) * 64 + ctz(LS));
+            X.w[j] = ~(c.ws | (table ? c.pipe : 0ull)) & V;
+            DG.w[j] = c.dig;
+            AL.w[j] = c.alp;
+        }
+    }
+    const u64 em = __ballot(my_end != 0xFFFFFFFFu);
+    u32 e;
+    if (em) e = readlane_u32(my_end, ctz(em));
+    else if (N <= (w0 + 64ull * W) * 64) e = (u32)(N - w0 * 64);
+    else return false;
+    const u32 s0 = (u32)(p & 63);
+#pragma unroll
+    for (int j = 0; j < W; j++) {   // the line's bytes: [s0, e) of the view
+        const u32 lo = (u32)((lane * W + j) * 64);
+        const u32 a = s0 > lo ? (s0 - lo < 64u ? s0 - lo : 64u) : 0u, b = e > lo ? (e - lo < 64u ? e - lo : 64u) : 0u;
+        const u64 m = below((int)b) & ~below((int)a);
+        X.w[j] &= m; DG.w[j] &= m; AL.w[j] &= m;
+    }
+    const WaveBits<W> K = g3_bits_solve(X, DG, AL, cfg.max_digit_ratio);
+    const WaveBits<W> KS = g3b_run_starts(K);   // kept tokens are whole tokens: the runs of K
+    int first_j = -1;
+#pragma unroll
+    for (int j = W - 1; j >= 0; j--) if (KS.w[j]) first_j = j;
+    const u64 fm = __ballot(first_j >= 0);
+    const int first_lane = fm ? ctz(fm) : -1;
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const u64 g = K.w[j];
+        if (g) {
+            const u64 wb = w0 + (u64)(lane * W + j);
+            u64 psp = KS.w[j], pnl = 0;
+            if (lane == first_lane && j == first_j) {   // the line's first kept token: a line break, if anything
+                const u64 low = psp & (0ull - psp);
+                psp &= ~low;
+                if (rab) pnl = low;
+            }
+            plan_or(plan, wb, g, g, psp, pnl);
+            atomicAdd(&tile_bytes[wb / SUB_BLOCKS], (u32)(popc(g) + popc(psp | pnl)));
+            atomicAdd(&tile_toks[wb / SUB_BLOCKS], (u32)popc(KS.w[j]));
+        }
+    }
+    return true;
+}
+
 // Lines that k_plan could not solve inside a tile (they cross a tile edge or are too long): twelve listed
 // lines per wavefront (one wavefront per workgroup).  Lane 5 * l + j re-classifies block j of line l's first
 // five blocks from global memory into the line's mask arrays in LDS; lane 5 * l then runs the same solver
@@ -1462,6 +1646,8 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
                                                      u32* tile_toks, u64* __restrict__ totals) {
     __shared__ u64 masks[G3S_LINES * G3S_STRIDE];
+    __shared__ u64 pend[G3S_LINES];   // lines of the group that are too long for one lane: entries of the list
+    __shared__ u32 npend;
     const int lane = threadIdx.x;
     u64 n = *mark_total;
     if (blockIdx.x == 0 && threadIdx.x == 0) { totals[4] = n; totals[5] = n > cap ? 1 : 0; }
@@ -1476,6 +1662,7 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
         const bool have = l < G3S_LINES && i < n;
         u64 p = 0;
         bool table = false, rab = false;
+        if (lane == 0) npend = 0;
         if (have) {
             const u64 ent = list[i];
             p = ent & 0xFFFFFFFFull;
@@ -1526,10 +1713,22 @@ __global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes
                     prevg = g >> 63;
                 }
             } else {
-                g3_serial_solve(bytes, offsets, R, N, cfg, plan, p, table, rab, tile_bytes, tile_toks);
+                pend[atomicAdd(&npend, 1u)] = list[i];
             }
         }
         __syncthreads();   // the line's lane has read the masks before the next group overwrites them
+        // the long lines of the group, one after the other, by the whole wavefront (up to 4 KiB, then up to 16 KiB);
+        // what is longer still is walked by one lane
+        const u32 np = npend;
+        for (u32 k = 0; k < np; k++) {   // uniform
+            const u64 ent = pend[k];
+            const u64 lp = ent & 0xFFFFFFFFull;
+            const bool ltable = (ent >> 32) & 1, lrab = (ent >> 33) & 1;
+            bool done = g3_wave_line<1>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
+            if (!done) done = g3_wave_line<4>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
+            if (!done && lane == 0) g3_serial_solve(bytes, offsets, R, N, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks);
+        }
+        __syncthreads();   // npend and pend are free again
     }
 }
 

@@ -1332,14 +1332,16 @@ TRP_HD void g3b_opaque(G3BitsT<W>& x) {
 }
 // The bytes of the tokens that strip_digit_tokens keeps (denoiser_preprocessor.rs:70-140).  X: bytes of
 // the line's tokens; DG / AL: its ASCII digits / alphabetic characters (one bit per character).
-template <int W>
-TRP_HD G3BitsT<W> g3_bits_solve(G3BitsT<W> X, const G3BitsT<W>& DG, const G3BitsT<W>& AL, float max_ratio) {
+// V is a bit vector type with the g3b_* operations: G3BitsT<W> (a line in the registers of one lane), or a
+// vector spread over the lanes of a wavefront.
+template <class V>
+TRP_HD V g3_bits_solve(V X, const V& DG, const V& AL, float max_ratio) {
     // seed: the tokens with a letter.  P = the first letter of each such token (the carry from the token
     // start runs through the letterless bytes Y and stops on a letter or on the separator after the token)
-    G3BitsT<W> K;
+    V K;
     {
-        const G3BitsT<W> Y = g3b_andn(X, AL);
-        const G3BitsT<W> P = g3b_and(g3b_andn(g3b_add(Y, g3b_run_starts(X)), Y), AL);
+        const V Y = g3b_andn(X, AL);
+        const V P = g3b_and(g3b_andn(g3b_add(Y, g3b_run_starts(X)), Y), AL);
         K = g3b_or(g3b_run_from(X, P), g3b_rev(g3b_run_from(g3b_rev(X), g3b_rev(P))));
     }
     const u32 a0 = g3b_popc_and(AL, X);
@@ -1349,12 +1351,12 @@ TRP_HD G3BitsT<W> g3_bits_solve(G3BitsT<W> X, const G3BitsT<W>& DG, const G3Bits
         // Z: kept bytes and everything that is not a token; a carry from a kept token's first (last) byte
         // stops on the first (last) byte of the next (previous) token that is not kept.  The kept tokens
         // are the runs of K.
-        const G3BitsT<W> Z = g3b_orn(K, X);
-        const G3BitsT<W> NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
-        G3BitsT<W> Wv = g3b_run_from(X, NS);
+        const V Z = g3b_orn(K, X);
+        const V NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
+        V Wv = g3b_run_from(X, NS);
         {
-            const G3BitsT<W> rZ = g3b_rev(Z);
-            const G3BitsT<W> rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
+            const V rZ = g3b_rev(Z);
+            const V rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
             Wv = g3b_or(Wv, g3b_rev(g3b_run_from(g3b_rev(X), rPE)));
         }
         if (!g3b_any(Wv)) break;
