@@ -432,6 +432,46 @@ def test_inputs_produced_on_the_callers_stream_need_no_sync(T):
         private.close()
 
 
+def test_long_digit_heavy_lines_by_length(T, ctx):
+    """Digit-heavy lines are solved by one lane up to 256 bytes, by a wavefront up to 4 KiB and up to 16 KiB, and
+    walked by one lane beyond: lengths on both sides of every limit, at several offsets against the 64-byte
+    blocks and across tile edges, plain and table rows, first line of a record and later lines, few and many
+    expansion rounds (letters at the start, in the middle, spread out), CRLF and end-of-record terminators."""
+    import random
+    rng = random.Random(11)
+
+    def digits_line(n, kind):
+        parts = []
+        size = 0
+        i = 0
+        while size < n:
+            if kind == 0:
+                w = "total" if i == 0 else str(rng.randint(0, 99999))
+            elif kind == 1:
+                w = "mid" if abs(size - n // 2) < 6 else str(rng.randint(0, 9999))
+            elif kind == 2:
+                w = "ab" if i % 9 == 0 else str(rng.randint(0, 999999))
+            else:
+                w = "| x%d |" % i if i % 11 == 0 else "| %d" % rng.randint(0, 99999)
+            parts.append(w)
+            size += len(w) + 1
+            i += 1
+        return " ".join(parts)[:n].rstrip() or "7 a"
+
+    recs = []
+    for n in (250, 256, 257, 300, 1000, 4000, 4090, 4096, 4100, 4200, 8000, 16000, 16380, 16390, 17000, 40000):
+        for kind in range(4):
+            pad = "x" * rng.randint(0, 70)
+            body = ["plain first line " + pad, digits_line(n, kind), "after the line", digits_line(n // 2 + 130, (kind + 1) % 4)]
+            recs.append("\n".join(body).encode())
+            recs.append((digits_line(n, kind) + "\r\nnext one").encode())          # first line of its record, CRLF
+            recs.append(("intro\n" + digits_line(n, kind)).encode())               # ends with its record
+    rng.shuffle(recs)
+    for cfg in ((True, 0.35, True, 32, (4,), 8), (True, 0.6, False, 1024, (64,), 512)):
+        exp, got = _run(T, ctx, recs, cfg)
+        assert_same(exp, got, recs, "long digit-heavy lines, ratio %s" % cfg[1])
+
+
 def test_device_entry_point_rejects_offsets_that_break_the_contract(T, ctx):
     """The device entry point cannot look at the offsets on the host: the first kernel checks them (start at 0,
     non-decreasing, end at n_bytes) and the call fails with an argument error instead of running away; the context
