@@ -1569,6 +1569,28 @@ __device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __r
                                     const UniTables& ut) {
     const int lane = threadIdx.x & 63;
     const u64 w0 = p >> 6;
+    // The first record start after p ends the line at the latest, and no other record start matters to it: one
+    // search by the whole wavefront (the records that start in the tiles of the view, 64 at a time) instead
+    // of one per block.
+    u64 next_rec = ~0ull;
+    {
+        const u64 nT = (N + TILE - 1) / TILE;
+        const u64 t0 = w0 / TILE_BLOCKS, last_blk = w0 + 64ull * W - 1;
+        u64 t1 = last_blk / TILE_BLOCKS + 1;
+        if (t1 > nT) t1 = nT;
+        u64 a = rec_lo[t0], b = rec_lo[t1];   // records [a, b) start in those tiles (all of them before N)
+        if (b > R) b = R;                     // (entries left behind by invalid offsets)
+        for (; a < b; a += 64) {              // uniform
+            const u64 r = a + (u64)lane;
+            const u64 q = r < b ? offsets[r] : ~0ull;
+            const u64 m = __ballot(r < b && q > p);
+            if (m) {
+                const int f = ctz(m);
+                next_rec = ((u64)readlane_u32((u32)(q >> 32), f) << 32) | readlane_u32((u32)q, f);
+                break;
+            }
+        }
+    }
     WaveBits<W> X, DG, AL;
     u32 my_end = 0xFFFFFFFFu;   // view-relative position of the first line start in this lane's blocks
 #pragma unroll
@@ -1581,8 +1603,8 @@ __device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __r
             const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
             const Cls c = classify_block_fast(blk, nvalid, ut);
             const u64 V = below(nvalid);
-            bool nrs;
-            const u64 RS = block_record_starts(offsets, rec_lo, R, N, wb, &nrs) & V;
+            const bool nrs = next_rec == q + 64;
+            const u64 RS = (next_rec >= q && next_rec < q + 64 ? 1ull << (next_rec - q) : 0ull) & V;
             const bool has_next = q + 64 < N;
             const bool next_nl = has_next && blk[64] == '\n' && !nrs;
             const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
@@ -1640,7 +1662,7 @@ __device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __r
 constexpr u32 G3_VIEW = G3_MAXW + 1;
 constexpr int G3S_LINES = 64 / G3_VIEW;             // lines per wavefront
 constexpr int G3S_STRIDE = 8 * (G3_VIEW + 1) + 1;   // u64 per line; odd, so that the lines spread over the banks
-__global__ __launch_bounds__(64) void k_gate3_solve(const u8* __restrict__ bytes,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_gate3_solve(const u8* __restrict__ bytes,
                                                      const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
                                                      PlanMem plan, const u64* __restrict__ list,
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
@@ -2929,7 +2951,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                      B.seedJ, B.seedS, dc, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
                                      ttoks, tflags, c->plan_stop()); }
             { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_gate3_solve, dim3(2048), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
+              hipLaunchKernelGGL(k_gate3_solve, dim3(4096), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
                                  B.g3list, totals + 6, B.g3_cap, tbytes, ttoks, totals); }
         } else {
             Prof pr(c, "k_count_tokens");
