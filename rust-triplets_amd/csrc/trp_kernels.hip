@@ -1555,6 +1555,81 @@ __device__ inline WaveBits<W> g3b_rev(const WaveBits<W>& a) {
 }
 template <int W>
 __device__ inline void g3b_opaque(WaveBits<W>&) {}
+
+// The same with one vector per DPP row: the 16 lanes of a row hold one 1 KiB vector, a wavefront four of them
+// (four lines solved side by side).  Carries, shifted-in bits and the mirror image stay inside the row.
+struct RowBits {
+    u64 w;
+};
+__device__ inline u32 row_prev_lane(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }   // row_shr:1
+__device__ inline u32 row_next_lane(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }   // row_shl:1
+__device__ inline u32 row_bits(u64 ballot) { return (u32)(ballot >> (threadIdx.x & 48)) & 0xFFFFu; }   // the row's part of a ballot
+__device__ inline RowBits g3b_and(const RowBits& a, const RowBits& b) { RowBits r = {a.w & b.w}; return r; }
+__device__ inline RowBits g3b_andn(const RowBits& a, const RowBits& b) { RowBits r = {a.w & ~b.w}; return r; }
+__device__ inline RowBits g3b_or(const RowBits& a, const RowBits& b) { RowBits r = {a.w | b.w}; return r; }
+__device__ inline RowBits g3b_orn(const RowBits& a, const RowBits& b) { RowBits r = {a.w | ~b.w}; return r; }
+__device__ inline bool g3b_any(const RowBits& a) { return row_bits(__ballot(a.w != 0)) != 0; }   // the same in the lanes of a row
+__device__ inline u32 g3b_popc_and(const RowBits& a, const RowBits& b) {   // the row's total, in every lane of the row
+    u32 n = (u32)popc(a.w & b.w);
+    n += (u32)__builtin_amdgcn_update_dpp(0, (int)n, 0x111, 0xf, 0xf, false);   // row_shr:1
+    n += (u32)__builtin_amdgcn_update_dpp(0, (int)n, 0x112, 0xf, 0xf, false);   // row_shr:2
+    n += (u32)__builtin_amdgcn_update_dpp(0, (int)n, 0x114, 0xf, 0xf, false);   // row_shr:4
+    n += (u32)__builtin_amdgcn_update_dpp(0, (int)n, 0x118, 0xf, 0xf, false);   // row_shr:8
+    return (u32)__shfl((int)n, (int)(threadIdx.x & 63) | 15, 64);
+}
+__device__ inline RowBits g3b_add(const RowBits& a, const RowBits& b) {
+    unsigned long long c = 0;
+    RowBits r;
+    r.w = __builtin_addcll(a.w, b.w, c, &c);
+    const u32 G = row_bits(__ballot(c != 0)), P = row_bits(__ballot(r.w == ~0ull));
+    const u32 V = (G << 1) & 0xFFFFu;
+    const u32 C = V | ((P + V) ^ P ^ V);
+    r.w += (C >> (threadIdx.x & 15)) & 1u;
+    return r;
+}
+__device__ inline RowBits g3b_run_starts(const RowBits& x) {
+    RowBits r = {x.w & ~((x.w << 1) | (u64)row_prev_lane((u32)(x.w >> 63)))};
+    return r;
+}
+__device__ inline RowBits g3b_run_ends(const RowBits& x) {
+    RowBits r = {x.w & ~((x.w >> 1) | ((u64)row_next_lane((u32)(x.w & 1ull)) << 63))};
+    return r;
+}
+__device__ inline RowBits g3b_run_from(const RowBits& x, const RowBits& points) { return g3b_andn(x, g3b_add(x, points)); }
+__device__ inline RowBits g3b_rev(const RowBits& a) {
+    const int lane = (int)(threadIdx.x & 63), src = (lane & 48) | (15 - (lane & 15));
+    const u32 lo = (u32)__shfl((int)(u32)a.w, src, 64), hi = (u32)__shfl((int)(u32)(a.w >> 32), src, 64);
+    RowBits r = {bitrev64((u64)lo | ((u64)hi << 32))};
+    return r;
+}
+// g3_bits_solve for four lines at once: the rows leave the expansion loop one by one (`active`), the wavefront
+// when the last one has.
+__device__ inline RowBits g3_rows_solve(const RowBits& X, const RowBits& DG, const RowBits& AL, float max_ratio, bool active) {
+    RowBits K;
+    {
+        const RowBits Y = g3b_andn(X, AL);
+        const RowBits P = g3b_and(g3b_andn(g3b_add(Y, g3b_run_starts(X)), Y), AL);
+        K = g3b_or(g3b_run_from(X, P), g3b_rev(g3b_run_from(g3b_rev(X), g3b_rev(P))));
+    }
+    const u32 a0 = g3b_popc_and(AL, X);
+    u32 d0 = g3b_popc_and(DG, K);
+    for (;;) {
+        const RowBits Z = g3b_orn(K, X);
+        const RowBits NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
+        RowBits Wv = g3b_run_from(X, NS);
+        {
+            const RowBits rZ = g3b_rev(Z);
+            const RowBits rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
+            Wv = g3b_or(Wv, g3b_rev(g3b_run_from(g3b_rev(X), rPE)));
+        }
+        const bool has = g3b_any(Wv);
+        const u32 wd = g3b_popc_and(DG, Wv);
+        active = active && has && !ratio_exceeds(d0 + wd, a0, max_ratio);
+        if (__ballot(active) == 0) break;   // uniform
+        if (active) { d0 += wd; K = g3b_or(K, Wv); }
+    }
+    return K;
+}
 }  // namespace trp
 
 namespace {
@@ -1655,6 +1730,89 @@ __device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __r
     return true;
 }
 
+// Up to four listed lines at once, one per DPP row: lane 16 r + l classifies block l of the 16-block view of line
+// ent[k0 + r].  Returns the rows whose line ended inside its view and was solved (bit r); the others are left
+// to g3_wave_line.  Every lane takes part.
+__device__ inline u32 g3_rows_lines(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                    const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, const DevCfg& cfg,
+                                    const PlanMem& plan, const u64* ent, u32 k0, u32 np, u32* tile_bytes, u32* tile_toks,
+                                    const UniTables& ut) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15, rowbase = lane & 48;
+    const bool have = k0 + (u32)row < np;
+    const u64 e64 = have ? ent[k0 + row] : 0;
+    const u64 p = e64 & 0xFFFFFFFFull;
+    const bool table = (e64 >> 32) & 1, rab = (e64 >> 33) & 1;
+    const u64 w0 = p >> 6, wb = w0 + (u64)l;
+    // the first record start after p (see g3_wave_line), searched by the row
+    u64 next_rec = ~0ull;
+    {
+        const u64 nT = (N + TILE - 1) / TILE;
+        u64 t1 = (w0 + 15) / TILE_BLOCKS + 1;
+        if (t1 > nT) t1 = nT;
+        u64 a = have ? rec_lo[w0 / TILE_BLOCKS] : 0, b = have ? rec_lo[t1] : 0;
+        if (b > R) b = R;
+        for (;;) {   // uniform
+            const u64 r = a + (u64)l;
+            const u64 q = r < b ? offsets[r] : ~0ull;
+            const u32 m = row_bits(__ballot(r < b && q > p));
+            const int f = rowbase + (m ? ctz((u64)m) : 0);
+            const u64 qf = ((u64)(u32)__shfl((int)(u32)(q >> 32), f, 64) << 32) | (u32)__shfl((int)(u32)q, f, 64);
+            if (m && next_rec == ~0ull) next_rec = qf;
+            a += 16;
+            if (__ballot(next_rec == ~0ull && a < b) == 0) break;
+        }
+    }
+    RowBits X = {0}, DG = {0}, AL = {0};
+    u32 my_end = 0xFFFFFFFFu;
+    if (have && wb < nB) {
+        const GuardBlk blk = {bytes, wb * 64, N};
+        const u64 q = wb * 64;
+        const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
+        const Cls c = classify_block_fast(blk, nvalid, ut);
+        const u64 V = below(nvalid);
+        const bool nrs = next_rec == q + 64;
+        const u64 RS = (next_rec >= q && next_rec < q + 64 ? 1ull << (next_rec - q) : 0ull) & V;
+        const bool has_next = q + 64 < N;
+        const bool next_nl = has_next && blk[64] == '\n' && !nrs;
+        const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
+        u64 LS = derive(c, V, RS, next_nl, pt).LS;
+        if (l == 0) LS &= ~below((int)(p & 63) + 1);
+        if (LS) my_end = (u32)(l * 64 + ctz(LS));
+        X.w = ~(c.ws | (table ? c.pipe : 0ull)) & V;
+        DG.w = c.dig;
+        AL.w = c.alp;
+    }
+    const u32 em = row_bits(__ballot(my_end != 0xFFFFFFFFu));
+    const u32 e_found = (u32)__shfl((int)my_end, rowbase + (em ? ctz((u64)em) : 0), 64);
+    u32 e = 0;
+    bool ok = have;
+    if (em) e = e_found;
+    else if (N <= (w0 + 16) * 64) e = (u32)(N - w0 * 64);
+    else ok = false;
+    {
+        const u32 s0 = (u32)(p & 63), lo = (u32)(l * 64);
+        const u32 a = s0 > lo ? (s0 - lo < 64u ? s0 - lo : 64u) : 0u, b = e > lo ? (e - lo < 64u ? e - lo : 64u) : 0u;
+        const u64 m = ok ? below((int)b) & ~below((int)a) : 0ull;
+        X.w &= m; DG.w &= m; AL.w &= m;
+    }
+    const RowBits K = g3_rows_solve(X, DG, AL, cfg.max_digit_ratio, ok);
+    const RowBits KS = g3b_run_starts(K);
+    const u32 fm = row_bits(__ballot(KS.w != 0));
+    if (ok && K.w) {
+        u64 psp = KS.w, pnl = 0;
+        if (fm && l == ctz((u64)fm)) {   // the line's first kept token: a line break, if anything
+            const u64 low = psp & (0ull - psp);
+            psp &= ~low;
+            if (rab) pnl = low;
+        }
+        plan_or(plan, wb, K.w, K.w, psp, pnl);
+        atomicAdd(&tile_bytes[wb / SUB_BLOCKS], (u32)(popc(K.w) + popc(psp | pnl)));
+        atomicAdd(&tile_toks[wb / SUB_BLOCKS], (u32)popc(KS.w));
+    }
+    const u64 okm = __ballot(ok);
+    return (u32)((okm & 1) | ((okm >> 15) & 2) | ((okm >> 30) & 4) | ((okm >> 45) & 8));
+}
+
 // Lines that k_plan could not solve inside a tile (they cross a tile edge or are too long): twelve listed
 // lines per wavefront (one wavefront per workgroup).  Lane 5 * l + j re-classifies block j of line l's first
 // five blocks from global memory into the line's mask arrays in LDS; lane 5 * l then runs the same solver
@@ -1742,13 +1900,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         // the long lines of the group, one after the other, by the whole wavefront (up to 4 KiB, then up to 16 KiB);
         // what is longer still is walked by one lane
         const u32 np = npend;
-        for (u32 k = 0; k < np; k++) {   // uniform
-            const u64 ent = pend[k];
-            const u64 lp = ent & 0xFFFFFFFFull;
-            const bool ltable = (ent >> 32) & 1, lrab = (ent >> 33) & 1;
-            bool done = g3_wave_line<1>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
-            if (!done) done = g3_wave_line<4>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
-            if (!done && lane == 0) g3_serial_solve(bytes, offsets, R, N, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks);
+        for (u32 k0 = 0; k0 < np; k0 += 4) {   // uniform: four lines at a time while they fit 1 KiB views
+            const u32 solved = g3_rows_lines(bytes, offsets, rec_lo, R, N, nB, cfg, plan, pend, k0, np, tile_bytes, tile_toks, ut);
+            for (u32 k = k0; k < np && k < k0 + 4; k++) {
+                if ((solved >> (k - k0)) & 1u) continue;
+                const u64 ent = pend[k];
+                const u64 lp = ent & 0xFFFFFFFFull;
+                const bool ltable = (ent >> 32) & 1, lrab = (ent >> 33) & 1;
+                bool done = g3_wave_line<1>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
+                if (!done) done = g3_wave_line<4>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
+                if (!done && lane == 0) g3_serial_solve(bytes, offsets, R, N, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks);
+            }
         }
         __syncthreads();   // npend and pend are free again
     }
