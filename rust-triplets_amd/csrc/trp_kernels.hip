@@ -2182,17 +2182,32 @@ struct EmitShared {
 static_assert(sizeof(SubRs) <= SUB + 64, "record-start words must fit in the output image");
 
 // Position where the token covering byte tS-1 starts (the sub-tile's first byte continues it): a walk back over
-// the token planes of the blocks before, at most to the start of the record.
+// the token planes of the blocks before, at most to the start of the record.  The whole wavefront walks, 64
+// blocks at a time (every lane calls this): the nearest block with a byte that is not a token byte, or with the
+// record start, answers.  (One lane walking alone made every sub-tile inside a token of megabytes - a base64
+// blob - take time in proportion to its distance from the token's start.)
 __device__ inline u64 find_token_start_before(const PlanCT* __restrict__ plan, u64 tS, u64 rec_start) {
-    u64 bb = tS / 64;
-    while (bb > 0) {
-        bb--;
-        u64 w = plan[bb].TOK & plan[bb].C;
-        u64 lo = bb * 64;
-        u64 allow = rec_start > lo ? ~below((int)(rec_start - lo)) : ~0ull;   // bits at/after the record start
-        u64 zero = ~w & allow;
-        if (zero) return lo + top(zero) + 1;
-        if (rec_start >= lo) return rec_start;
+    const int lane = threadIdx.x & 63;
+    long long nearest = (long long)(tS / 64) - 1;
+    while (nearest >= 0) {   // uniform
+        const long long bb = nearest - lane;
+        bool cand = false;
+        u64 ans = 0;
+        if (bb >= 0) {
+            const u64 w = plan[bb].TOK & plan[bb].C;
+            const u64 lo = (u64)bb * 64;
+            // bits at/after the record start (a lane beyond the block that holds it is never the nearest answer)
+            const u64 allow = rec_start > lo ? (rec_start - lo < 64 ? ~below((int)(rec_start - lo)) : 0ull) : ~0ull;
+            const u64 zero = ~w & allow;
+            if (zero) { cand = true; ans = lo + (u64)top(zero) + 1; }
+            else if (rec_start >= lo) { cand = true; ans = rec_start; }
+        }
+        const u64 m = __ballot(cand);
+        if (m) {
+            const int f = ctz(m);
+            return ((u64)readlane_u32((u32)(ans >> 32), f) << 32) | readlane_u32((u32)ans, f);
+        }
+        nearest -= 64;
     }
     return rec_start;
 }
@@ -2315,16 +2330,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_
     const u32 tot_a = readlane_u32(inc_a, 63), tot_nte = readlane_u32(inc_e, 63);
     const u32 total_nb = out0 + (tot_a & 0xFFFFu);
     const u32 shift = PASSTHROUGH ? 0 : (out0 & 15u);
-    // does a token run into this sub-tile from the left?  Lane 0 finds where it starts.
+    // does a token run into this sub-tile from the left?  Where it starts matters only when it also ends here
+    // (the sub-tile with the end writes the token's table entry): the first token end of the sub-tile comes
+    // before its first token start.
     const bool runs_in = readlane_u32((u32)(((TOKC & 1u) && prev_tok && !(RS & 1u)) ? 1u : 0u), 0) != 0;
-    if (tid == 0 && runs_in) {
-        // the last record that starts before the sub-tile, as a position in the previous block (or -1)
+    bool need_start = false;
+    if (runs_in) {   // uniform
+        const u64 bte = __ballot(TE != 0), bts = __ballot(TS != 0);
+        if (bte) {
+            const int la = ctz(bte);
+            if (!bts || la < ctz(bts)) need_start = true;
+            else if (la == ctz(bts)) need_start = readlane_u32((u32)(__builtin_ctz(TE | 0x80000000u) < __builtin_ctz(TS | 0x80000000u) ? 1u : 0u), la) != 0;
+        }
+    }
+    if (need_start) {   // uniform
+        // lane 0: the last record that starts before the sub-tile, as a position in the previous block (or -1)
         const long long rp = (prev_rec + 64 >= tS && prev_rec < tS) ? (long long)(prev_rec + 64 - tS) : -1;
         const u64 zeros = ~prev_w;   // bit 63 of prev_w is set
         const long long z = zeros ? top(zeros) + 1 : -1;
         const long long at = z > rp ? z : rp;   // start position inside the previous block, if it can be told from there
-        if (at >= 0) sh.cin_start = tS - 64 + (u64)at;
-        else sh.cin_start = find_token_start_before(plan.ct, tS, prev_rec);
+        const int at0 = (int)readlane_u32((u32)(int)at, 0);
+        if (at0 >= 0) {
+            if (tid == 0) sh.cin_start = tS - 64 + (u64)at0;
+        } else {
+            const u64 rec0_start = readlane_u32((u32)prev_rec, 0);   // a batch is shorter than 4 GiB
+            const u64 start = find_token_start_before(plan.ct, tS, rec0_start);
+            if (tid == 0) sh.cin_start = start;
+        }
     }
     if (stop_after == 2) return;
     // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes

@@ -303,7 +303,10 @@ def test_token_density_around_the_staged_table_of_a_sub_tile(T, ctx):
     mixed = [(b"w " * 1500 + b"longtoken" * 1500 + b" x y z " + b"q" * 4096 + b" " + b"r s " * 900)]
     edges = [b"ab " * 1365 + b"c", b"d" * 4096, b"e f " * 1024, b"", b"g" * 4095 + b" ", b"h i"] * 3
     crowded = [b"k l"] * 5000 + [b"m" * 70] * 300 + [b"n o p q\n12 34 56 ab\n"] * 2000
-    for recs in (dense, mixed, edges, crowded, dense + mixed + edges + crowded):
+    # tokens of hundreds of KB (their start is looked up from the sub-tile where they end, 64 blocks at a time):
+    # starting at a record start, after a short word, ending at a record end, followed by more text
+    blobs = [b"x" * 300000 + b" y", b"a " + b"z" * 70001, b"w" * 5000, b"pre\n" + b"Q" * 200003 + b"\nafter it", b"v" * 4097]
+    for recs in (dense, mixed, edges, crowded, blobs, dense + mixed + blobs + edges + crowded):
         for cfg in ((True, 0.35, True, 16, (4, 2), 8), (False, 0.35, True, 1024, (64,), 512)):
             exp, got = _run(T, ctx, recs, cfg)
             assert_same(exp, got, recs, "token density, denoiser %s" % cfg[0])
