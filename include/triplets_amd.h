@@ -182,8 +182,9 @@ int trp_wait_batch(trp_ctx* ctx, trp_result* out);
  * fixed scratch array that is part of the library's code object (about 25 MiB on each GPU the library is loaded
  * on, held until the process ends), and every result array is the caller's device memory, described by
  * trp_out_buffers:
- *   denoised (16-byte aligned, denoised_cap >= n_bytes bytes; unused with the denoiser disabled, where the text
- *   is the input itself), denoised_offsets / tok_offsets / chunk_offsets (n_records + 1 entries each), dropped
+ *   denoised (16-byte aligned, denoised_cap >= n_bytes bytes, all of which the kernels may use as working space:
+ *   the text is its first n_denoised bytes afterwards; unused with the denoiser disabled, where the text is the
+ *   input itself), denoised_offsets / tok_offsets / chunk_offsets (n_records + 1 entries each), dropped
  *   (n_records), tok_start / tok_len (tok_cap >= trp_token_bound(n_bytes, n_records) entries each), chunks
  *   (chunk_cap entries).
  * Limits: n_bytes <= TRP_NOALLOC_MAX_BYTES and n_records <= TRP_NOALLOC_MAX_RECORDS (TRP_E_TOO_LARGE beyond;

@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(NT) void k_tile_carry(const J* __restrict__ SA, u64
 
 // ---- digit-heavy lines solved inside the tile (one wavefront per line) ---------------------------
 constexpr u32 G3_LCAP = 1024;   // lines per tile that can be listed in LDS
-constexpr u32 G3_MAXW = G3_WORDS;   // the mask solver takes lines of up to 64 * G3_MAXW bytes; longer ones are walked serially
+constexpr u32 G3_MAXW = G3_WORDS;   // one lane's mask solver takes lines of up to 64 * G3_MAXW bytes; longer ones are solved by lanes together
 
 
 // Per-block masks of the tile, kept in the LDS region of the (no longer needed) byte image.
@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_gate3: solve the digit-heavy lines that k_plan marked (one lane per marked line, serial walk).
+// k_gate3: solve the digit-heavy lines that k_plan left on the work list.
 // ---------------------------------------------------------------------------------------------------
 __device__ inline void plan_or(const PlanMem& plan, u64 word, u64 c, u64 tok, u64 psp, u64 pnl) {
     if (c) atomicOr(reinterpret_cast<unsigned long long*>(&plan.ct[word].C), c);
@@ -1411,7 +1411,8 @@ __device__ inline void plan_or(const PlanMem& plan, u64 word, u64 c, u64 tok, u6
 }
 
 // Serial solver for one listed line (any length): lane-local walk over the bytes, results OR-ed into
-// the plan with atomics.
+// the plan with atomics.  Slow (microseconds per byte); only used when there is no output buffer to hold the
+// vectors of g3_huge_line.
 __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* __restrict__ offsets, u64 R, u64 N,
                                        const DevCfg& cfg, const PlanMem& plan, u64 p, bool table, bool rab,
                                        u32* tile_bytes, u32* tile_toks) {
@@ -1730,6 +1731,193 @@ __device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __r
     return true;
 }
 
+// ---- digit-heavy lines of any length -----------------------------------------------------------------
+// The same solver streamed over the line in pieces of 64 blocks (4 KiB), lane i taking block i of the piece.
+// Its bit vectors live in memory, four words per block (token bytes X, digits DG, kept bytes K, the bytes the
+// current expansion round would add W): in the part of the output buffer that belongs to the line's own bytes
+// [p, e) - k_emit fills the output later, nothing else touches that part now, and 32 bytes per 64-byte block
+// fit.  A multi-word addition runs through the pieces with its carry; the mirrored additions run through them
+// from the last piece to the first.  Seeding takes one pass each way, every expansion round one pass each way
+// (the round's W is merged into K by the next round's first pass), the result one more.
+struct HugeWords {
+    u64 X, DG, K, W;
+};
+// a + b + cin over the 64 words of the lanes (lane 0 lowest); *cout = the carry out of lane 63
+__device__ inline u64 wave_add_carry(u64 a, u64 b, u32 cin, u32* cout) {
+    unsigned long long c = 0;
+    u64 r = __builtin_addcll(a, b, c, &c);
+    const u64 G = __ballot(c != 0), P = __ballot(r == ~0ull);
+    const u64 V = (G << 1) | cin;
+    const u64 C = V | ((P + V) ^ P ^ V);
+    *cout = (u32)(((G >> 63) | ((P >> 63) & (C >> 63))) & 1ull);
+    r += (C >> (threadIdx.x & 63)) & 1ull;
+    return r;
+}
+__device__ inline u64 wave_mirror(u64 v) {   // the 4096-bit vector of the wavefront, end for end
+    const int src = 63 - (int)(threadIdx.x & 63);
+    const u32 lo = (u32)__shfl((int)(u32)v, src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
+    return bitrev64((u64)lo | ((u64)hi << 32));
+}
+__device__ inline u32 wave_popc_total(u64 v) { return readlane_u32(wave_incl_scan_add((u32)popc(v)), 63); }
+
+__device__ inline void g3_huge_line(const u8* __restrict__ bytes, const u64* __restrict__ offsets, u64 R, u64 N, u64 nB,
+                                    const DevCfg& cfg, const PlanMem& plan, u8* __restrict__ scratch_text, u64 p, bool table,
+                                    bool rab, u32* tile_bytes, u32* tile_toks, const UniTables& ut) {
+    const int lane = threadIdx.x & 63;
+    const u64 w0 = p >> 6;
+    const u32 s0 = (u32)(p & 63);
+    HugeWords* H = reinterpret_cast<HugeWords*>(scratch_text + ((p + 7) & ~7ull));
+    // end of the record that holds p (the first record start after p ends the line at the latest)
+    u64 rec_end;
+    {
+        u64 lo = 0, hi = R;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid;
+        }
+        rec_end = offsets[lo + 1];
+    }
+    // ---- first pass: classify, find the line's end, seed (the part of every token with a letter from its first
+    // letter on), store X / DG / K; W holds the first letters for the way back
+    u64 nchunks = 0, e = 0;   // e: end of the line relative to the view's first byte
+    u32 a0 = 0;
+    {
+        u32 c1 = 0, c2 = 0, last_x = 0;
+        for (u64 c = 0;; c++) {   // uniform
+            const u64 bi = c * 64 + (u64)lane, wb = w0 + bi, q = wb * 64;
+            Cls cl = {0, 0, 0, 0, 0, 0, 0};
+            u64 LS = 0, V = 0;
+            if (wb < nB) {
+                const GuardBlk blk = {bytes, q, N};
+                const int nvalid = (int)((N - q) < 64 ? (N - q) : 64);
+                cl = classify_block_fast(blk, nvalid, ut);
+                V = below(nvalid);
+                const bool nrs = rec_end == q + 64;
+                const u64 RS = (rec_end >= q && rec_end < q + 64 ? 1ull << (rec_end - q) : 0ull) & V;
+                const bool next_nl = q + 64 < N && blk[64] == '\n' && !nrs;
+                const bool pt = prev_is_term(q > 0, blk[-1], nvalid > 0, blk[0], (RS & 1ull) != 0);
+                LS = derive(cl, V, RS, next_nl, pt).LS;
+                if (bi == 0) LS &= ~below((int)s0 + 1);
+            }
+            const u64 em = __ballot(LS != 0);
+            bool last = false;
+            if (em) {
+                const int f = ctz(em);
+                e = (c * 64 + (u64)f) * 64 + (u64)readlane_u32((u32)ctz(LS | (1ull << 63)), f);
+                last = true;
+            } else if ((w0 + (c + 1) * 64) * 64 >= N) {
+                e = N - w0 * 64;
+                last = true;
+            }
+            const u64 lo = bi * 64;
+            const u64 from = (u64)s0 > lo ? ((u64)s0 - lo < 64 ? (u64)s0 - lo : 64) : 0;
+            const u64 to = last ? (e > lo ? (e - lo < 64 ? e - lo : 64) : 0) : 64;
+            const u64 m = below((int)to) & ~below((int)from);
+            const u64 X = ~(cl.ws | (table ? cl.pipe : 0ull)) & V & m, DG = cl.dig & m, AL = cl.alp & m;
+            a0 += wave_popc_total(AL & X);
+            const u64 Y = X & ~AL;
+            const u32 x_before = from_prev_lane((u32)(X >> 63));   // (read by every lane, outside any select)
+            const u64 S = X & ~((X << 1) | (lane == 0 ? (u64)last_x : (u64)x_before));
+            const u64 P = wave_add_carry(Y, S, c1, &c1) & ~Y & AL;
+            const u64 Kf = X & ~wave_add_carry(X, P, c2, &c2);
+            if (!last || lo < e) { const HugeWords hw = {X, DG, Kf, P}; H[bi] = hw; }
+            last_x = readlane_u32((u32)(X >> 63), 63);
+            nchunks = c + 1;
+            if (last) break;
+        }
+    }
+    const u64 nblk = (e + 63) / 64;   // blocks of the view that hold bytes of the line
+    // ---- way back: the part of every token with a letter before its first letter; the digits kept so far
+    u32 d0 = 0;
+    {
+        u32 cb = 0;
+        for (u64 c = nchunks; c-- > 0;) {
+            const u64 bi = c * 64 + (u64)lane;
+            HugeWords hw = {0, 0, 0, 0};
+            if (bi < nblk) hw = H[bi];
+            const u64 rX = wave_mirror(hw.X);
+            const u64 Kb = wave_mirror(rX & ~wave_add_carry(rX, wave_mirror(hw.W), cb, &cb));
+            hw.K |= Kb;
+            hw.W = 0;
+            if (bi < nblk) H[bi] = hw;
+            d0 += wave_popc_total(hw.DG & hw.K);
+        }
+    }
+    // ---- expansion rounds (denoiser_preprocessor.rs:94-131)
+    bool merge = false;   // the previous round was accepted: its W belongs to K
+    for (;;) {
+        {
+            u32 c1 = 0, c2 = 0, last_k = 0;
+            for (u64 c = 0; c < nchunks; c++) {
+                const u64 bi = c * 64 + (u64)lane;
+                HugeWords hw = {0, 0, 0, 0};
+                if (bi < nblk) hw = H[bi];
+                if (merge) hw.K |= hw.W;
+                const u64 Z = hw.K | ~hw.X;
+                const u32 k_before = from_prev_lane((u32)(hw.K >> 63));
+                const u64 S = hw.K & ~((hw.K << 1) | (lane == 0 ? (u64)last_k : (u64)k_before));
+                const u64 NS = wave_add_carry(Z, S, c1, &c1) & ~Z;
+                hw.W = hw.X & ~wave_add_carry(hw.X, NS, c2, &c2);
+                if (bi < nblk) H[bi] = hw;
+                last_k = readlane_u32((u32)(hw.K >> 63), 63);
+            }
+        }
+        u32 wd = 0;
+        u64 any = 0;
+        {
+            u32 c1 = 0, c2 = 0, next_k = 0;
+            for (u64 c = nchunks; c-- > 0;) {
+                const u64 bi = c * 64 + (u64)lane;
+                HugeWords hw = {0, 0, 0, 0};
+                if (bi < nblk) hw = H[bi];
+                const u32 k_after = from_next_lane((u32)(hw.K & 1ull));
+                const u64 E = hw.K & ~((hw.K >> 1) | ((lane == 63 ? (u64)next_k : (u64)k_after) << 63));
+                const u64 rZ = wave_mirror(hw.K | ~hw.X);
+                const u64 rPE = wave_add_carry(rZ, wave_mirror(E), c1, &c1) & ~rZ;
+                const u64 rX = wave_mirror(hw.X);
+                hw.W |= wave_mirror(rX & ~wave_add_carry(rX, rPE, c2, &c2));
+                if (bi < nblk) H[bi].W = hw.W;
+                any |= __ballot(hw.W != 0);
+                wd += wave_popc_total(hw.DG & hw.W);
+                next_k = readlane_u32((u32)(hw.K & 1ull), 0);
+            }
+        }
+        if (!any) break;
+        if (ratio_exceeds(d0 + wd, a0, cfg.max_digit_ratio)) break;
+        d0 += wd;
+        merge = true;
+    }
+    // ---- the kept tokens into the plan
+    {
+        u32 last_k = 0;
+        bool first_done = false;
+        for (u64 c = 0; c < nchunks; c++) {
+            const u64 bi = c * 64 + (u64)lane;
+            u64 K = 0;
+            if (bi < nblk) K = H[bi].K;
+            const u32 k_before = from_prev_lane((u32)(K >> 63));
+            const u64 KS = K & ~((K << 1) | (lane == 0 ? (u64)last_k : (u64)k_before));
+            const u64 fm = __ballot(KS != 0);
+            u64 psp = KS, pnl = 0;
+            if (!first_done && fm) {
+                if (lane == ctz(fm)) {   // the line's first kept token: a line break, if anything
+                    const u64 low = psp & (0ull - psp);
+                    psp &= ~low;
+                    if (rab) pnl = low;
+                }
+                first_done = true;
+            }
+            if (K) {
+                const u64 wb = w0 + bi;
+                plan_or(plan, wb, K, K, psp, pnl);
+                atomicAdd(&tile_bytes[wb / SUB_BLOCKS], (u32)(popc(K) + popc(psp | pnl)));
+                atomicAdd(&tile_toks[wb / SUB_BLOCKS], (u32)popc(KS));
+            }
+            last_k = readlane_u32((u32)(K >> 63), 63);
+        }
+    }
+}
+
 // Up to four listed lines at once, one per DPP row: lane 16 r + l classifies block l of the 16-block view of line
 // ent[k0 + r].  Returns the rows whose line ended inside its view and was solved (bit r); the others are left
 // to g3_wave_line.  Every lane takes part.
@@ -1816,7 +2004,8 @@ __device__ inline u32 g3_rows_lines(const u8* __restrict__ bytes, const u64* __r
 // Lines that k_plan could not solve inside a tile (they cross a tile edge or are too long): twelve listed
 // lines per wavefront (one wavefront per workgroup).  Lane 5 * l + j re-classifies block j of line l's first
 // five blocks from global memory into the line's mask arrays in LDS; lane 5 * l then runs the same solver
-// as k_plan, or walks the line serially when it has more than G3_MAXW blocks.
+// as k_plan; lines of more than G3_MAXW blocks are then solved by the lanes together (g3_rows_lines, g3_wave_line,
+// g3_huge_line).
 constexpr u32 G3_VIEW = G3_MAXW + 1;
 constexpr int G3S_LINES = 64 / G3_VIEW;             // lines per wavefront
 constexpr int G3S_STRIDE = 8 * (G3_VIEW + 1) + 1;   // u64 per line; odd, so that the lines spread over the banks
@@ -1824,7 +2013,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                                                      const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
                                                      PlanMem plan, const u64* __restrict__ list,
                                                      const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
-                                                     u32* tile_toks, u64* __restrict__ totals) {
+                                                     u32* tile_toks, u64* __restrict__ totals, u8* __restrict__ scratch_text) {
     __shared__ u64 masks[G3S_LINES * G3S_STRIDE];
     __shared__ u64 pend[G3S_LINES];   // lines of the group that are too long for one lane: entries of the list
     __shared__ u32 npend;
@@ -1909,7 +2098,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 const bool ltable = (ent >> 32) & 1, lrab = (ent >> 33) & 1;
                 bool done = g3_wave_line<1>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
                 if (!done) done = g3_wave_line<4>(bytes, offsets, rec_lo, R, N, nB, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks, ut);
-                if (!done && lane == 0) g3_serial_solve(bytes, offsets, R, N, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks);
+                if (!done) {
+                    if (scratch_text) g3_huge_line(bytes, offsets, R, N, nB, cfg, plan, scratch_text, lp, ltable, lrab, tile_bytes, tile_toks, ut);
+                    else if (lane == 0) g3_serial_solve(bytes, offsets, R, N, cfg, plan, lp, ltable, lrab, tile_bytes, tile_toks);
+                }
             }
         }
         __syncthreads();   // npend and pend are free again
@@ -3146,7 +3338,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                      ttoks, tflags, c->plan_stop()); }
             { Prof pr(c, "k_gate3");
               hipLaunchKernelGGL(k_gate3_solve, dim3(4096), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
-                                 B.g3list, totals + 6, B.g3_cap, tbytes, ttoks, totals); }
+                                 B.g3list, totals + 6, B.g3_cap, tbytes, ttoks, totals, B.denoised); }
         } else {
             Prof pr(c, "k_count_tokens");
             hipLaunchKernelGGL(k_count_tokens, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, plan, tbytes,
