@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How much do wide numeric table rows cost?  Config B's text with one digit-heavy row of 300-600 bytes appended
 to every record (one per 4 KB): such rows are longer than the 256 bytes one lane solves and go to the
-wavefront-per-line solver of k_gate3_solve.  Prints GB/s and the per-kernel times."""
+solvers of k_gate3_solve in which lanes work together.  Other lengths: tools/wide_rows_bench.py LO HI.
+Prints GB/s and the per-kernel times."""
 import os
 import random
 import sys
@@ -15,6 +16,7 @@ import corpusgen
 import triplets_amd as T
 
 rng = random.Random(3)
+LO, HI = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (300, 600)   # row length in bytes
 data, offs = corpusgen.config_b(200_000_000, 42, 16)[:2]
 raw = bytes(data)
 parts = []
@@ -22,7 +24,7 @@ noffs = [0]
 size = 0
 for r in range(len(offs) - 1):
     rec = raw[offs[r]:offs[r + 1]]
-    n = rng.randint(300, 600)
+    n = rng.randint(LO, HI)
     row = "| Item %d | " % r + " | ".join("%d,%03d.%02d" % (rng.randint(1, 999), rng.randint(0, 999), rng.randint(0, 99))
                                           for _ in range(n // 12)) + " | Total |"
     rec = rec + b"\n" + row.encode()
