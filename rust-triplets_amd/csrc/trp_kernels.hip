@@ -2316,7 +2316,7 @@ struct SubRegs {
     uint4 v[SUB / 16 / 64];
 };
 __device__ inline void sub_load(const u8* __restrict__ g, u64 N, u64 sS, SubRegs& r) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (sS + SUB <= N) {
         const uint4* src = reinterpret_cast<const uint4*>(g + sS);
 #pragma unroll
@@ -2327,7 +2327,7 @@ __device__ inline void sub_load(const u8* __restrict__ g, u64 N, u64 sS, SubRegs
     for (int k = 0; k < SUB / 16 / 64; k++) r.v[k] = load16_guarded(g, N, sS + (u64)(k * 64 + lane) * 16);
 }
 __device__ inline void sub_store(const SubRegs& r, u8* sb) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < SUB / 16 / 64; k++) {
         const int c = k * 64 + lane;   // 16-byte chunk c: half block c / 2, its first or second 16 bytes
@@ -2339,7 +2339,7 @@ __device__ inline u32 sub_rs_fetch(const u64* __restrict__ offsets, const u32* _
                                    RsFetch& f) {
     const RecRange g = rec_range(rec_lo_w, s, R);
     const u32 r0 = g.r0, r1 = g.r1;
-    const u64 r = (u64)r0 + threadIdx.x;
+    const u64 r = (u64)r0 + (threadIdx.x & 63);
     f.q = ~0u;
     f.n = r1 - r0;
     if (r <= r1 && r < R) f.q = (u32)offsets[r];
@@ -2352,11 +2352,11 @@ __device__ inline void sub_rs_set(SubRs& rs, u64 q, u64 N, u64 sS) {
 __device__ inline void sub_rs_store(const RsFetch& f, const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w,
                                     u64 R, u64 N, u64 s, SubRs& rs) {
     const u64 sS = s * (u64)SUB;
-    for (int i = threadIdx.x; i <= 64; i += 64) rs.w[i] = 0;
+    for (int i = threadIdx.x & 63; i <= 64; i += 64) rs.w[i] = 0;
     if (f.q != ~0u) sub_rs_set(rs, f.q, N, sS);
     if (f.n >= 64) {   // crowded sub-tile: the rest of its records
         const u64 r0 = rec_range(rec_lo_w, s, R).r0, r1 = (u64)r0 + f.n;
-        for (u64 r = r0 + 64 + threadIdx.x; r <= r1 && r < R; r += 64) sub_rs_set(rs, offsets[r], N, sS);
+        for (u64 r = r0 + 64 + (threadIdx.x & 63); r <= r1 && r < R; r += 64) sub_rs_set(rs, offsets[r], N, sS);
     }
 }
 
@@ -2420,7 +2420,7 @@ struct EmitIn {
 __device__ inline void emit_fetch(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                   const u32* __restrict__ rec_lo_w, u64 R, const PlanMem& plan,
                                   const u64* __restrict__ tile_base, u64 N, u64 nB, u64 s, bool passthrough, EmitIn& in) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const u64 b = s * (u64)SUB_BLOCKS + (lane >> 1);
     if (!passthrough) sub_load(bytes, N, s * (u64)SUB, in.regs);   // nothing is copied when the denoiser is off
     const u32 r0 = sub_rs_fetch(offsets, rec_lo_w, R, s, in.rf);
@@ -2451,25 +2451,30 @@ __device__ inline u32 wave_incl_scan_max(u32 v) {
 }
 __device__ inline u32 below32(u32 j) { return j >= 32 ? ~0u : ((1u << j) - 1u); }   // bits < j
 
-// One wavefront per workgroup and sub-tile (2 KiB), one lane per 32 bytes.  Nothing crosses wavefronts, so there
-// are no workgroup barriers: a wavefront only orders its own LDS traffic, and the waves of a CU drift apart and
-// overlap each other's load, compute and store phases.  The kernel is latency-bound: its time falls with the
+// One wavefront per sub-tile (2 KiB), one lane per 32 bytes.  Nothing crosses wavefronts, so there are no
+// workgroup barriers: a wavefront only orders its own LDS traffic, and the waves of a CU drift apart and overlap
+// each other's load, compute and store phases.  A workgroup is WAVES such wavefronts that share nothing but
+// their launch: one-wave workgroups left the kernel waiting for the workgroup dispatcher (487,000 workgroups per
+// GB: 0.72 / 0.69 / 0.67 / 0.68 / 0.72 ms for 1 / 2 / 4 / 8 / 16 waves per workgroup on 1 GB of English text).  The kernel is latency-bound: its time falls with the
 // number of resident waves (1.05 / 0.83 / 0.75 / 0.69 ms at 9 / 12 / 15 / 18 waves per CU with 64-byte lanes on
 // 1 GB of English text), hence the small lanes: 4.4 KB of LDS and about 50 VGPRs per wave allow 8 per SIMD.
 // (Several sub-tiles per wavefront with the loads of the next one in flight were measured slower: fresh
 // wavefronts hide the load latency better than the registers a prefetch holds.)
 // PASSTHROUGH: the denoiser is off, the text is the input itself: nothing is copied, k_count_tokens has left the
 // token plane in the plan.
-template <bool PASSTHROUGH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_emit(const u8* __restrict__ bytes,
+constexpr int EMIT_WAVES = 4;
+template <bool PASSTHROUGH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8))) void k_emit(const u8* __restrict__ bytes,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
                                               u64 N, u64 nB, u64 nW, PlanMem plan,
                                               const u64* __restrict__ tile_base, u8* __restrict__ denoised,
                                               u32* __restrict__ tok_start, u32* __restrict__ tok_len,
                                               u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
-    __shared__ EmitShared sh;
-    const int tid = threadIdx.x;   // = lane
-    const u64 t = blockIdx.x;
+    __shared__ EmitShared shw[WAVES];
+    EmitShared& sh = shw[threadIdx.x >> 6];
+    const int tid = threadIdx.x & 63;   // = lane
+    const u64 t = (u64)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (t >= nW) return;
     SubRs& srs = *reinterpret_cast<SubRs*>(sh.out);
     EmitIn in;
     emit_fetch(bytes, offsets, rec_lo_w, R, plan, tile_base, N, nB, t, PASSTHROUGH, in);
@@ -3348,12 +3353,13 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
           const GenTiles gen = {tbytes, ttoks, tflags, B.packed};
           if ((rc = scan_gen(st, B.partial, gen, B.packed, nW, tile_base))) return rc; }
         { Prof pr(c, "k_emit");
+          const dim3 grid((unsigned)((nW + EMIT_WAVES - 1) / EMIT_WAVES)), block(64 * EMIT_WAVES);
           if (pass)
-              hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
+              hipLaunchKernelGGL((k_emit<true, EMIT_WAVES>), grid, block, 0, st, d_bytes,
                                  d_offsets, B.rec_lo_w, R, N, nB, nW, plan, tile_base, (u8*)nullptr, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop());
           else
-              hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)nW), dim3(64), 0, st, d_bytes,
+              hipLaunchKernelGGL((k_emit<false, EMIT_WAVES>), grid, block, 0, st, d_bytes,
                                  d_offsets, B.rec_lo_w, R, N, nB, nW, plan, tile_base, B.denoised, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop()); }
     }

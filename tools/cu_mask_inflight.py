@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--split", type=int, default=128)
     ap.add_argument("--bytes", type=int, default=1_000_000_000)
+    ap.add_argument("--no-masks", action="store_true", help="only the runs on unmasked streams")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -98,7 +99,7 @@ def main():
     print("in flight, two contexts, all CUs, second context 0.6 ms out of phase: %.1f GB/s" % in_flight(one, two, 0.0006),
           flush=True)
     k = args.split
-    for name, a, b in (("contiguous", range(0, k), range(k, n_cu)),
+    for name, a, b in () if args.no_masks else (("contiguous", range(0, k), range(k, n_cu)),
                        ("interleaved", [c for c in range(n_cu) if (c * k // n_cu) != ((c + 1) * k // n_cu)],
                         [c for c in range(n_cu) if (c * k // n_cu) == ((c + 1) * k // n_cu)])):
         a, b = list(a), list(b)
