@@ -153,15 +153,19 @@ def run_in_flight(T, device, batches, den, st, steps, warmup, stagger_s=0.0):
                                      + (", the second %.2f ms out of phase" % (stagger_s * 1e3) if stagger_s else "")}
 
 
-def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup):
+def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup, normalize=False):
     """One more single-GPU workload on the same context: timed like the headline one (blocking calls,
-    synchronize on both sides), then a profiled pass for the per-kernel durations."""
+    synchronize on both sides), then a profiled pass for the per-kernel durations.  normalize: time
+    normalize_inline_whitespace (trp_normalize_batch_device) instead of the path."""
     import torch
 
     def step(after_batch=None):
         d = t = c = 0
         for d_bytes, d_offs, r, n in batches:
-            res = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
+            if normalize:
+                res = ctx.normalize_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n)
+            else:
+                res = ctx.preprocess_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), r, n, den, st)
             d, t, c = d + int(res.n_denoised), t + int(res.n_tokens), c + int(res.n_chunks)
             if after_batch is not None:
                 after_batch()
@@ -177,12 +181,13 @@ def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup):
     elapsed = time.perf_counter() - t0
     N, R, nb = sum(b[3] for b in batches), sum(b[2] for b in batches), len(batches)
     ms = elapsed / steps * 1e3
-    stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled}
+    stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled or normalize}
     kern = kernel_profile(ctx, step, nb, 3)
     roof = roofline_of(kern, stats, nb, ms)
-    if nb == 1:
+    if nb == 1 and not normalize:
         roof["traffic"] = committed_traffic(workload, N, den.enabled, roof["kernel"])
     return {"workload": workload, "value": round(N * steps / elapsed / 1e9, 2), "unit": "GB/s",
+            "denoiser": "normalize_inline_whitespace" if normalize else ("enabled" if den.enabled else "disabled"),
             "ms_per_step": round(ms, 4), "steps": steps, "bytes": N, "records": R, "batches_per_step": nb,
             "overlap_tokens": list(st.overlap_tokens),
             "outputs": {"denoised_bytes": res[0], "tokens": res[1], "chunks": res[2]},
@@ -417,6 +422,14 @@ def main():
 
         def to_dev(dd, oo):
             return (torch.from_numpy(dd).cuda(), torch.from_numpy(oo.astype(np.int64)).cuda(), int(len(oo) - 1), int(len(dd)))
+
+        # config B a second time with the denoiser disabled (tokenise + chunk only), and the step before the
+        # path (normalize_inline_whitespace) over the same batch
+        ex["B_denoiser_disabled"] = run_extra(T, ctx, "B", workload, batches,
+                                              T.DenoiserConfig(enabled=False, max_digit_ratio=0.35, strip_markdown=True),
+                                              st, args.steps, args.warmup)
+        ex["B_normalize_inline_whitespace"] = run_extra(T, ctx, "B", workload, batches, den, st, args.steps, args.warmup,
+                                                        normalize=True)
 
         dd, oo = corpusgen.config_c(4_000_000_000, 43, threads)
         bt = [to_dev(dd, oo)]
