@@ -98,6 +98,9 @@ def main():
     print("in flight, two contexts, all CUs: %.1f GB/s" % in_flight(one, two), flush=True)
     print("in flight, two contexts, all CUs, second context 0.6 ms out of phase: %.1f GB/s" % in_flight(one, two, 0.0006),
           flush=True)
+    same = T.Context(0, stream=one.stream)   # a second context on the first one's stream: the batches run one after
+    print("in flight, two contexts on one stream: %.1f GB/s" % in_flight(one, same), flush=True)   # the other, no idle GPU between them
+    same.close()
     k = args.split
     for name, a, b in () if args.no_masks else (("contiguous", range(0, k), range(k, n_cu)),
                        ("interleaved", [c for c in range(n_cu) if (c * k // n_cu) != ((c + 1) * k // n_cu)],
