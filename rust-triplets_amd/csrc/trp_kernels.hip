@@ -2607,9 +2607,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
         // output position of the (copied) byte at bit j: the lane's base plus the bit index, minus the bytes
         // dropped below j, plus the separators inserted up to j
         const u32 base = PASSTHROUGH ? (u32)(p - tS) : ex_nb - out0;   // relative to out0
-        const u32 drops = PASSTHROUGH ? 0u : ~Cm, pfx = PASSTHROUGH ? 0u : PFX;
+        // (bit j is a copied byte, so the bits below it are all valid: j minus the dropped bytes below it is the
+        // number of copied bytes below it)
+        const u32 pfx = PASSTHROUGH ? 0u : PFX;
         auto pos = [&](u32 j) -> u32 {
-            return base + j - (u32)__builtin_popcount(drops & ((1u << j) - 1u)) + (u32)__builtin_popcount(pfx & ((2u << j) - 1u));
+            if (PASSTHROUGH) return base + j;
+            return base + (u32)__builtin_popcount(Cm & ((1u << j) - 1u)) + (u32)__builtin_popcount(pfx & ((2u << j) - 1u));
         };
         u32 ts = TS, te = TE;
         u32 idx = ex_ntk;   // index of the next token that starts in this lane
