@@ -8,7 +8,8 @@ A step is one pass of the whole path (all kernels of trp_preprocess_batch_device
 batch that is already resident in HBM.  Workload at every N: BASELINE.json configs[1] - 1.0e9 bytes of
 synthetic ASCII English, records of 3072-5120 bytes, denoiser enabled, default chunking - per GPU
 (weak scaling: records shard by range, no inter-GPU traffic in the timed region).  Rank 0 prints one
-JSON line.
+JSON line.  Before the W warm-up steps every workload runs untimed passes for 50 ms ("settle_ms"): a GPU that
+sat idle while the host generated the corpus takes about 25 ms of load to reach its steady clocks.
 
 --config E is BASELINE.json configs[4]: a 64e9-byte corpus (OCR-noisy markdown generator) cut by record
 range into one shard per GPU (strong scaling); a shard is held in HBM as slices of at most 4e9 bytes,
@@ -27,6 +28,21 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "corpusgen"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+# A GPU that has been idle (here: while the host generates the corpus) needs about 25 ms of load before its
+# clocks reach their steady state: the first twenty blocking calls on 1 GB run 1.44 ... 1.20 ms
+# (tools/step_times.py).  Every workload therefore runs untimed passes for SETTLE_S seconds before its W warm-up
+# steps, so that the W / K the caller chose measure the steady rate; the JSON line says so ("settle_ms").
+SETTLE_S = 0.05
+
+
+def settle(step):
+    """Untimed passes until SETTLE_S seconds of GPU work have gone by (at least two)."""
+    t0, n = time.perf_counter(), 0
+    while n < 2 or time.perf_counter() - t0 < SETTLE_S:
+        step()
+        n += 1
+    return n
 
 # Algorithmic HBM bytes of each kernel per launch: what the path has to move through that kernel once, from the
 # batch figures (N input bytes, D denoised bytes, T tokens, R records).  Passes the implementation chose to make
@@ -139,6 +155,7 @@ def run_in_flight(T, device, batches, den, st, steps, warmup, stagger_s=0.0):
             if busy[j]:
                 cs[j].wait_batch()
 
+    settle(lambda: passes(1))
     passes(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -171,6 +188,7 @@ def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup, normalize
                 after_batch()
         return d, t, c
 
+    settle(step)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -326,6 +344,7 @@ def main():
                 reap(j, pend[j])
         return tuple(tot)
 
+    settle_steps = settle(lambda: run_steps(1))   # clocks up (see SETTLE_S); then the caller's W and K
     if args.warmup:
         run_steps(args.warmup)
     torch.cuda.synchronize()
@@ -366,7 +385,8 @@ def main():
     out = {
         "metric": "device-resident GB/s of text denoised+tokenised+chunked",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "warmup": args.warmup, "settle_ms": SETTLE_S * 1e3, "settle_steps": settle_steps,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if args.config == "E" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R, "batches_per_step": nb,
                    "denoiser": "normalize_inline_whitespace" if args.normalize else ("enabled" if den.enabled else "disabled"),
