@@ -2503,6 +2503,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
     const u32 RS = srs.w[tid] & V;
     const bool next_rs = !(p + HALF < N) || (srs.w[tid + 1] & 1u);
     wave_lds_sync();   // the record-start words are in registers: their space is the output image from here on
+    if (!PASSTHROUGH) {   // the image starts out as zeros (the run copies OR their partial dwords into it)
+        uint4* z = reinterpret_cast<uint4*>(sh.out);
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        z[tid] = zero;
+        z[tid + 64] = zero;
+        if (tid < (int)((SUB + 64) / 16 - 128)) z[tid + 128] = zero;
+    }
     // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every sub-tile after that phase
     if (stop_after == 1) return;
     // the neighbours' edge bits through the cross-lane network
@@ -2556,10 +2563,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
         }
     }
     if (stop_after == 2) return;
-    // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes
-    // with no separator inside; its source is contiguous in the lane's half block and its destination is
-    // contiguous in the output image, so it moves as (unaligned source, aligned destination) dwords.
+    wave_lds_sync();   // the image is zero in every lane's view before anything is ORed into it
+    // bytes -> LDS output image, one copy run at a time.  A run is a maximal stretch of copied bytes with no
+    // separator inside; its source is contiguous in the lane's half block and its destination is contiguous in
+    // the output image.  The image starts out as zeros and a run moves as whole dwords of the image: the dwords
+    // it covers completely are stored, the one or two it shares with its neighbours (other runs, separators,
+    // other lanes) are ORed in with the bytes outside the run masked off - no byte-sized accesses, no loops over
+    // bytes.  The source of image dword k is the unaligned dword at a fixed distance in the half block: two
+    // aligned dwords shifted in registers (LDS accesses that straddle a dword stall the whole LDS pipeline).
     if (!PASSTHROUGH) {
+        u32* img = reinterpret_cast<u32*>(sh.out);
+        const u32* srcw = reinterpret_cast<const u32*>(blk);   // 8 dwords and a spare one; the slot is dword aligned
         u32 o = ex_nb - out0 + shift;
         u32 brk = Cm & (PFX | ~(Cm << 1));
         while (brk) {
@@ -2568,33 +2582,37 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
             const u32 rest = ~Cm >> a0;
             u32 len = rest ? (u32)__builtin_ctz(rest) : 32u - a0;
             if (brk) { const u32 nbk = (u32)__builtin_ctz(brk) - a0; if (nbk < len) len = nbk; }
-            if ((PFX >> a0) & 1u) { sh.out[o] = ((PNL >> a0) & 1u) ? '\n' : ' '; o++; }
-            const u8* src = blk + a0;
-            u8* dst = sh.out + o;
-            u32 head = (4u - (o & 3u)) & 3u;
-            if (head > len) head = len;
-            for (u32 i = 0; i < head; i++) dst[i] = src[i];
-            const u32 nd = (len - head) >> 2;
-            // destination dwords are aligned; the source is read as aligned dwords and shifted in
-            // registers (LDS accesses that straddle a dword stall the whole LDS pipeline).  Four dwords
-            // at a time (five source dwords), the rest one by one.
-            const u32 sa = (a0 + head) & 3u;            // the half block itself is dword aligned
-            const u8* sbase = src + head - sa;
-            const u32 ng = nd >> 2;
-            for (u32 q = 0; q < ng; q++) {
-                const u32* sp = reinterpret_cast<const u32*>(sbase + 16 * q);
-                const u32 w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
-                u32* dp = reinterpret_cast<u32*>(dst + head + 16 * q);
-                dp[0] = __builtin_amdgcn_alignbyte(w1, w0, sa);
-                dp[1] = __builtin_amdgcn_alignbyte(w2, w1, sa);
-                dp[2] = __builtin_amdgcn_alignbyte(w3, w2, sa);
-                dp[3] = __builtin_amdgcn_alignbyte(w4, w3, sa);
+            if ((PFX >> a0) & 1u) {
+                atomicOr(&img[o >> 2], (((PNL >> a0) & 1u) ? (u32)'\n' : (u32)' ') << (8u * (o & 3u)));
+                o++;
             }
-            for (u32 k = ng * 4; k < nd; k++) {
-                const Pair32 w = *reinterpret_cast<const Pair32*>(sbase + 4 * k);
-                *reinterpret_cast<u32*>(dst + head + 4 * k) = __builtin_amdgcn_alignbyte(w.hi, w.lo, sa);
+            const u32 e = o + len - 1u;                    // last image byte of the run
+            const u32 d = o & 3u, D0 = o >> 2, nd = (e >> 2) - D0;   // nd + 1 image dwords
+            const int s0 = (int)a0 - (int)d;               // source byte of image dword D0's first byte: -3 .. 31
+            const u32 sa = (u32)s0 & 3u;
+            const int q0 = s0 >> 2;                        // aligned source dword of that byte: -1 .. 7
+            const u32 mf = 0xFFFFFFFFu << (8u * d), ml = 0xFFFFFFFFu >> (8u * (3u - (e & 3u)));
+            // (source bytes before the half block only ever land in the bytes that mf masks off: dword -1 is not read)
+            const u32* sp = srcw + q0;
+            u32* dp = img + D0;
+            u32 w0 = srcw[q0 < 0 ? 0 : q0], w1 = sp[1];
+            const u32 v0 = __builtin_amdgcn_alignbyte(w1, w0, sa) & mf;
+            if (nd == 0) {
+                atomicOr(dp, v0 & ml);
+            } else {
+                atomicOr(dp, v0);
+                u32 k = 1;   // next image dword; its source dwords are sp[k], sp[k + 1]
+                if (nd >= 5) {   // four whole dwords at once
+                    const u32 x1 = sp[1], x2 = sp[2], x3 = sp[3], x4 = sp[4], x5 = sp[5];
+                    dp[1] = __builtin_amdgcn_alignbyte(x2, x1, sa);
+                    dp[2] = __builtin_amdgcn_alignbyte(x3, x2, sa);
+                    dp[3] = __builtin_amdgcn_alignbyte(x4, x3, sa);
+                    dp[4] = __builtin_amdgcn_alignbyte(x5, x4, sa);
+                    k = 5;
+                }
+                for (; k < nd; k++) dp[k] = __builtin_amdgcn_alignbyte(sp[k + 1], sp[k], sa);   // at most three
+                atomicOr(dp + nd, __builtin_amdgcn_alignbyte(sp[nd + 1], sp[nd], sa) & ml);
             }
-            for (u32 i = head + 4 * nd; i < len; i++) dst[i] = src[i];
             o += len;
         }
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dynamic instruction counts of k_emit per phase (cumulative), per wave (a wave handles EMIT_TPW tiles).
 export TMPDIR=/tmp
-for d in 1 2 3 4 5 0; do
+for d in ${PHASES:-1 2 3 6 4 5 0}; do
   OUT=gpurun_out/pmc_ep$d
   rm -rf $OUT
   TRP_PROFILE_EMIT_STOP=$d timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH -f csv -d $OUT -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > $OUT.json 2> $OUT.log || exit 1
