@@ -2519,10 +2519,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
     const u32 TS = TOKC & (~((TOKC << 1) | (prev_tok ? 1u : 0u)) | RS);
     const u32 TE = TOKC & (~((TOKC >> 1) | (next_tok ? 0x80000000u : 0u)) | ((RS >> 1) | (next_rs ? 0x80000000u : 0u)));
     // wave prefix sums: emitted bytes | token starts << 16, token ends; prefix maximum: last token start + 1
-    const u32 me_nb = (u32)__builtin_popcount(Cm) + (u32)__builtin_popcount(PFX), me_ntk = (u32)__builtin_popcount(TS),
-              me_nte = (u32)__builtin_popcount(TE);
+    const u32 me_nb = (u32)__builtin_popcount(Cm) + (u32)__builtin_popcount(PFX), me_ntk = (u32)__builtin_popcount(TS);
     const u32 me_a = me_nb | (me_ntk << 16);
-    const u32 inc_a = wave_incl_scan_add(me_a), inc_e = wave_incl_scan_add(me_nte);
+    const u32 inc_a = wave_incl_scan_add(me_a);
     const u32 inc_l = wave_incl_scan_max(TS ? (u32)(tid * HALF + 31 - __builtin_clz(TS) + 1) : 0u);
     const u32 out0 = PASSTHROUGH ? (u32)tS : (u32)(tb64 & 0xFFFFFFFFull);   // output position of the sub-tile's first byte
     const u32 tok0 = (u32)(tb64 >> 32);                                      // index of the first token that starts in it
@@ -2531,13 +2530,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
     const u32 up_l = (u32)__shfl_up((int)inc_l, 1, 64);   // every lane takes part
     const u32 ex_l = tid > 0 ? up_l : 0u;
     const int ex_lts = (int)ex_l - 1;   // sub-tile-relative position of the last token start before this lane, -1 none
-    const u32 tot_a = readlane_u32(inc_a, 63), tot_nte = readlane_u32(inc_e, 63);
+    const u32 tot_a = readlane_u32(inc_a, 63);
     const u32 total_nb = out0 + (tot_a & 0xFFFFu);
     const u32 shift = PASSTHROUGH ? 0 : (out0 & 15u);
     // does a token run into this sub-tile from the left?  Where it starts matters only when it also ends here
     // (the sub-tile with the end writes the token's table entry): the first token end of the sub-tile comes
     // before its first token start.
     const bool runs_in = readlane_u32((u32)(((TOKC & 1u) && prev_tok && !(RS & 1u)) ? 1u : 0u), 0) != 0;
+    // token ends of the sub-tile: every token that starts or runs in also ends here, unless it runs on
+    const bool runs_out = readlane_u32((u32)(((TOKC >> 31) && next_tok && !next_rs) ? 1u : 0u), 63) != 0;
+    const u32 tot_nte = (tot_a >> 16) + (runs_in ? 1u : 0u) - (runs_out ? 1u : 0u);
     bool need_start = false;
     if (runs_in) {   // uniform
         const u64 bte = __ballot(TE != 0), bts = __ballot(TS != 0);
