@@ -176,9 +176,11 @@ int trp_submit_batch_device(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t
                             uint64_t n_records, uint64_t n_bytes, const trp_config* cfg);
 int trp_wait_batch(trp_ctx* ctx, trp_result* out);
 
-/* trp_preprocess_batch_device for callers that cannot allocate GPU memory at the time of the call (code under
- * HIP graph capture or in a tight serving loop, harnesses that forbid hipMalloc).  It has no counterpart in the
- * reference.  The call allocates and frees nothing, on the device or the host: every working array lives in a
+/* trp_preprocess_batch_device for callers that cannot allocate GPU memory at the time of the call (tight
+ * serving loops, harnesses that forbid hipMalloc, processes whose device memory is fully budgeted).  It has no
+ * counterpart in the reference.  It is a blocking call like trp_preprocess_batch_device: it synchronises the
+ * context's stream and reads the batch totals on the host, so it cannot be recorded into a HIP graph (stream
+ * capture rejects the synchronise).  The call allocates and frees nothing, on the device or the host: every working array lives in a
  * fixed scratch array that is part of the library's code object (about 25 MiB on each GPU the library is loaded
  * on, held until the process ends), and every result array is the caller's device memory, described by
  * trp_out_buffers:
@@ -193,7 +195,9 @@ int trp_wait_batch(trp_ctx* ctx, trp_result* out);
  * are identical to trp_preprocess_batch_device; `out` points into the caller's buffers.  The call returns after
  * the kernels have completed, like trp_preprocess_batch_device.  All calls on one GPU share that GPU's scratch
  * array, from whatever context or thread: calls that overlap in time on one GPU race and must be serialised by
- * the caller.  The other entry points do not use the array. */
+ * the caller.  The other entry points do not use the array.  The batch becomes "the last device-resident batch" of
+ * the context: the text renderers below (which do allocate their own output) read it through the caller's
+ * buffers, which must therefore stay untouched until the next batch call on the context. */
 #define TRP_NOALLOC_MAX_BYTES (32ull << 20)
 #define TRP_NOALLOC_MAX_RECORDS (1ull << 19)
 typedef struct {

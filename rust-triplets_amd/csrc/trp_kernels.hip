@@ -1423,7 +1423,8 @@ __device__ inline void g3_serial_solve(const u8* __restrict__ bytes, const u64* 
         u64 mid = (lo + hi) >> 1;
         if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid;
     }
-    u64 rec_end = offsets[lo + 1];
+    u64 rec_end = lo < R ? offsets[lo + 1] : N;   // (lo == R only with offsets that break the contract)
+    if (rec_end > N) rec_end = N;
     u64 e = p;
     while (e < rec_end) {
         u32 ch = src.get(e);
@@ -1775,7 +1776,8 @@ __device__ inline void g3_huge_line(const u8* __restrict__ bytes, const u64* __r
             const u64 mid = (lo + hi) >> 1;
             if (offsets[mid + 1] <= p) lo = mid + 1; else hi = mid;
         }
-        rec_end = offsets[lo + 1];
+        rec_end = lo < R ? offsets[lo + 1] : N;   // (lo == R only with offsets that break the contract)
+        if (rec_end > N) rec_end = N;
     }
     // ---- first pass: classify, find the line's end, seed (the part of every token with a letter from its first
     // letter on), store X / DG / K; W holds the first letters for the way back
@@ -3591,6 +3593,7 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
         return fail(TRP_E_ARG, "token arrays must hold trp_token_bound(n_bytes, n_records) entries");
     if (ob->chunk_cap && !ob->chunks) return fail(TRP_E_ARG, "chunks is null");
     HIPCHK(hipSetDevice(c->device));
+    c->have_last = false;   // whatever happens, the previous batch is no longer "the last batch" of this context
     unsigned char* sp = c->scratch_ptr;   // never the array's name: that is not a device address on the host
     if (!sp) return fail(TRP_E_HIP, "scratch array address unknown");
     constexpr ScratchLayout L = scratch_layout();
@@ -3653,6 +3656,11 @@ int trp_preprocess_batch_device_noalloc(trp_ctx* c, const uint8_t* d_bytes, cons
     out->tok_offsets = ob->tok_offsets;
     out->chunks = ob->chunks;
     out->chunk_offsets = ob->chunk_offsets;
+    // the text renderers (trp_materialize_chunk_text_device, ...) work on the last batch of the context: this one,
+    // through the caller's buffers (they allocate their own output; only the batch call itself allocates nothing)
+    c->last = *out;
+    c->last_R = R;
+    c->have_last = true;
     return TRP_OK;
 }
 

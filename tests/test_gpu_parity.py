@@ -504,3 +504,17 @@ def test_device_entry_point_rejects_offsets_that_break_the_contract(T, ctx):
         got = ctx.preprocess_batch_device(db.data_ptr(), do.data_ptr(), R, N, den, st).to_host()
         exp = O.batch(data, offs, O.make_config(den.enabled, 0.35, True, 16, (3,), 4))
         assert_same(exp, got, recs, "after rejected batches, denoiser %s" % den.enabled)
+    # a digit-heavy line of more than 16 KiB (the streamed gate-3 solver, which looks for the end of its record in
+    # the offsets) in a batch whose last offset lies before the line: rejected, nothing read beyond offsets[R]
+    long_line = ("12 34 ab 56 " * 3400).encode()
+    dl = torch.from_numpy(np.concatenate([np.frombuffer(long_line, np.uint8), np.zeros(64, np.uint8)])).cuda()
+    for bad in ([0, 8], [0, 0], [0, 3, 8]):
+        do = torch.tensor(bad, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        with pytest.raises(T.TripletsAmdError):
+            ctx.preprocess_batch_device(dl.data_ptr(), do.data_ptr(), len(bad) - 1, len(long_line), den_on, st)
+    do = torch.tensor([0, len(long_line)], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    got = ctx.preprocess_batch_device(dl.data_ptr(), do.data_ptr(), 1, len(long_line), den_on, st).to_host()
+    d1, o1 = O.pack([long_line])
+    assert_same(O.batch(d1, o1, O.make_config(True, 0.35, True, 16, (3,), 4)), got, [long_line], "long line after rejects")

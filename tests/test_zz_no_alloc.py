@@ -54,6 +54,16 @@ def _compare(T, torch, ctx, recs, den, st):
     assert got.tok_start == keep["tok_start"].data_ptr() and got.chunks == keep["chunks"].data_ptr()
     got = got.to_host()
     assert (got.n_denoised, got.n_tokens, got.n_chunks) == (ref.n_denoised, ref.n_tokens, ref.n_chunks)
+    # the batch is now the context's "last device batch": the chunk text renderer reads it through the caller's buffers
+    tptr, optr, nbytes = ctx.materialize_chunk_text()
+    toff = np.empty(got.n_chunks + 1, dtype=np.uint64)
+    text = np.empty(nbytes, dtype=np.uint8)
+    L = T.load_library()
+    assert L.trp_copy_to_host(ctx._h, toff.ctypes.data, optr, toff.nbytes) == 0
+    if nbytes:
+        assert L.trp_copy_to_host(ctx._h, text.ctypes.data, tptr, text.nbytes) == 0
+    for c in range(0, got.n_chunks, max(1, got.n_chunks // 200)):
+        assert text[int(toff[c]):int(toff[c + 1])].tobytes() == ref.chunk_text(c), c
     assert_same(ref, got, recs, "no-alloc entry point vs trp_preprocess_batch_device")
     # and both against the oracle
     exp = O.batch(data, offs, O.make_config(den.enabled, den.max_digit_ratio, den.strip_markdown,
