@@ -4,6 +4,10 @@
   python bench.py --gpus N --steps K --warmup W          (N=1 by default)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher (no WORLD_SIZE in the environment) with --gpus N > 1, the script starts the N ranks
+itself, one fresh process per GPU, before anything touches a GPU, and fails loudly when fewer than N GPUs are
+visible: it never reports a one-GPU number under a multi-GPU request.
+
 A step is one pass of the whole path (all kernels of trp_preprocess_batch_device) over one packed
 batch that is already resident in HBM.  Workload at every N: BASELINE.json configs[1] - 1.0e9 bytes of
 synthetic ASCII English, records of 3072-5120 bytes, denoiser enabled, default chunking - per GPU
@@ -170,7 +174,7 @@ def run_in_flight(T, device, batches, den, st, steps, warmup, stagger_s=0.0):
                                      + (", the second %.2f ms out of phase" % (stagger_s * 1e3) if stagger_s else "")}
 
 
-def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup, normalize=False):
+def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup, normalize=False, traffic_workload=None):
     """One more single-GPU workload on the same context: timed like the headline one (blocking calls,
     synchronize on both sides), then a profiled pass for the per-kernel durations.  normalize: time
     normalize_inline_whitespace (trp_normalize_batch_device) instead of the path."""
@@ -202,14 +206,69 @@ def run_extra(T, ctx, name, workload, batches, den, st, steps, warmup, normalize
     stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled or normalize}
     kern = kernel_profile(ctx, step, nb, 3)
     roof = roofline_of(kern, stats, nb, ms)
-    if nb == 1 and not normalize:
-        roof["traffic"] = committed_traffic(workload, N, den.enabled, roof["kernel"])
+    # HBM bytes per launch from the committed counter runs of this very workload (traffic_workload: the name the
+    # workload has when it is the main one of a run, i.e. in the profile's own bench line)
+    if (nb == 1 or traffic_workload) and not normalize:
+        roof["traffic"] = committed_traffic(traffic_workload or workload, N, den.enabled, roof["kernel"])
     return {"workload": workload, "value": round(N * steps / elapsed / 1e9, 2), "unit": "GB/s",
             "denoiser": "normalize_inline_whitespace" if normalize else ("enabled" if den.enabled else "disabled"),
             "ms_per_step": round(ms, 4), "steps": steps, "bytes": N, "records": R, "batches_per_step": nb,
             "overlap_tokens": list(st.overlap_tokens),
             "outputs": {"denoised_bytes": res[0], "tokens": res[1], "chunks": res[2]},
             "roofline": roof}
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, env=None, timeout=None):
+    """Start `argv` (a command line) as n fresh processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set the way torch.distributed.run sets them, wait for all of them and return the largest exit
+    status.  The caller must not have initialised a GPU: the children are new processes (no fork of GPU state, no
+    exec from a process that holds one).  When a rank fails the others are stopped (by their own PIDs)."""
+    import subprocess
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": str(free_port())})
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen(argv, env=e))
+    t_end = None if timeout is None else time.time() + timeout
+    worst, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            worst = max(worst, abs(rc))
+            if rc != 0:
+                for q in live:
+                    q.terminate()
+        if t_end is not None and time.time() > t_end:
+            for q in live:
+                q.kill()
+            worst = max(worst, 124)
+            t_end = None
+        time.sleep(0.05)
+    return worst
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: check that N GPUs are there, then run the N ranks."""
+    import torch
+    have = torch.cuda.device_count()   # counting devices does not initialise one
+    if "TRP_BENCH_DEVICE" not in os.environ and have < n:
+        raise SystemExit("bench.py: --gpus %d asked for but %d GPU(s) visible; refusing to report a smaller run "
+                         "as a %d-GPU one" % (n, have, n))
+    rc = launch_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    raise SystemExit(rc)
 
 
 def main():
@@ -233,6 +292,10 @@ def main():
                     help="skip the other single-GPU workloads (configs C, D, E on one GPU, host-memory path) that "
                          "the default one-GPU run reports next to the headline value")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)   # does not return
 
     import numpy as np
     import torch
@@ -242,13 +305,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
     # Rehearsal aids (never set by the driver): TRP_BENCH_DEVICE pins every rank to one GPU and
     # TRP_BENCH_BACKEND=gloo replaces RCCL, so that the multi-rank code path can run on a one-GPU box.
     device = int(os.environ.get("TRP_BENCH_DEVICE", local_rank))
     backend = os.environ.get("TRP_BENCH_BACKEND", "nccl")
+    if device >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but %d GPU(s) are visible" % (rank, device, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
@@ -344,29 +409,41 @@ def main():
                 reap(j, pend[j])
         return tuple(tot)
 
-    settle_steps = settle(lambda: run_steps(1))   # clocks up (see SETTLE_S); then the caller's W and K
-    if args.warmup:
-        run_steps(args.warmup)
-    torch.cuda.synchronize()
+    def timed(k):
+        """K steps bracketed by barrier + synchronize on both sides; the time is the maximum over the ranks."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = run_steps(k)                 # returns after every batch of every step has completed
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, r
+
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = run_steps(args.steps)          # returns after every batch of every step has completed
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         nn = torch.tensor([N], dtype=torch.float64, device="cuda")
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         total_bytes = float(nn.item())
     else:
         total_bytes = float(N)
+    # first the plain reading: W warm-up steps and K timed steps straight after the corpus was generated (the GPU
+    # has been idle and is still clocking up), reported as "value_no_settle" ...
+    if args.warmup:
+        run_steps(args.warmup)
+    elapsed_cold, _ = timed(args.steps)
+    # ... then the steady rate: untimed passes for SETTLE_S, the caller's W, the caller's K
+    settle_steps = settle(lambda: run_steps(1))
+    if args.warmup:
+        run_steps(args.warmup)
+    elapsed, res = timed(args.steps)
 
     stats = {"N": N, "R": R, "D": res[0], "T": res[1], "C": res[2], "enabled": den.enabled}
     per_launch = {k: (v // nb if k != "enabled" else v) for k, v in stats.items()}   # average batch of the shard
@@ -386,6 +463,7 @@ def main():
         "metric": "device-resident GB/s of text denoised+tokenised+chunked",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "settle_ms": SETTLE_S * 1e3, "settle_steps": settle_steps,
+        "value_no_settle": round(total_bytes * args.steps / elapsed_cold / 1e9, 2),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong" if args.config == "E" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": workload, "bytes_per_gpu": N, "records_per_gpu": R, "batches_per_step": nb,
@@ -477,7 +555,9 @@ def main():
             bt.append(to_dev(dd, oo))
             del dd, oo
         ex["E_1gpu"] = run_extra(T, ctx, "E", "config E on one GPU: the first 8.0e9 B of the 64e9 B corpus' shard 0 "
-                                 "(config-C generator, seeds 45, 46), 2 slices of 4e9 B per step", bt, den, st, 3, 1)
+                                 "(config-C generator, seeds 45, 46), 2 slices of 4e9 B per step", bt, den, st, 3, 1,
+                                 traffic_workload="config E: %.1e B synthetic OCR-noisy markdown corpus, one record-range "
+                                                  "shard per GPU, %d slice(s) of <= 4e9 B per shard" % (8_000_000_000, 2))
         del bt
         torch.cuda.empty_cache()
         out["configs"] = ex

@@ -98,6 +98,11 @@ typedef struct {
  * usable gfx950 device is present: there is no CPU fallback. */
 int trp_create(int device, trp_ctx** out);
 void trp_destroy(trp_ctx* ctx);
+/* Number of GPUs the HIP runtime shows to this process (0 when there is none or the runtime fails).  For hosts
+ * that spread a batch over all GPUs by record range, one context and one thread per device: records are
+ * independent (ChunkingAlgorithm::materialize takes one section, src/chunking/algorithm.rs:7-13), so the shards
+ * share nothing. */
+int trp_device_count(void);
 const char* trp_last_error(void);
 /* The hipStream_t the context launches on (as void*), for callers that order their own work. */
 void* trp_stream(trp_ctx* ctx);
@@ -260,6 +265,30 @@ int trp_chunk_bodies_device(trp_ctx* ctx, const uint32_t* chunk_index, const uin
 int trp_bm25_texts_device(trp_ctx* ctx, const uint64_t* doc_offsets, uint64_t n_docs, uint32_t max_tokens,
                           const char* newline, uint8_t** d_text, uint64_t** d_text_offsets,
                           uint64_t* n_text_bytes);
+
+/* The two steps above for callers whose texts live in host memory (the reference's call sites do: decorate_chunk at
+ * src/sampler/mod.rs:1470-1508 / :1582-1620 works on a RecordChunk's String, record_bm25_text at
+ * src/sampler/backends/bm25_backend.rs:503-532 on a DataRecord's sections).  Each call copies the packed batch to
+ * the GPU, runs it as ONE device batch (at most TRP_MAX_BATCH_BYTES; no sub-batching), renders the requested texts
+ * there and returns them in library-owned host memory (release with trp_chunk_text_free): out->offsets has n + 1
+ * (n_docs + 1) entries.
+ * trp_head_tokens_text: trp_head_tokens_text_device over the batch's records as they are (no denoiser): text r is
+ *   record r when it has at most max_tokens tokens, else its first max_tokens tokens joined by one space - the
+ *   BM25 query cap with max_tokens = 64 (src/sampler/backends/bm25_backend.rs:219-225).
+ * trp_bm25_texts: the records of the batch are the headings and section texts of the documents in order, as for
+ *   trp_bm25_texts_device; the texts are tokenised as they are (no denoiser: record_bm25_text applies none).
+ * trp_chunk_bodies: the batch is preprocessed and chunked with `cfg` exactly as trp_preprocess_batch does, then
+ *   chunk chunk_index[i] of that result is cut to budget[i] tokens as for trp_chunk_bodies_device.  (chunk_index
+ *   refers to the batch's chunk order: a caller that does not know it yet calls trp_preprocess_batch_select with
+ *   TRP_OUT_CHUNKS first, or uses the device variants, which keep the batch on the GPU between the two steps.) */
+int trp_head_tokens_text(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                         uint32_t max_tokens, trp_chunk_text* out);
+int trp_bm25_texts(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                   const uint64_t* doc_offsets, uint64_t n_docs, uint32_t max_tokens, const char* newline,
+                   trp_chunk_text* out);
+int trp_chunk_bodies(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                     const trp_config* cfg, const uint32_t* chunk_index, const uint32_t* budget, uint64_t n,
+                     trp_chunk_text* out);
 
 /* normalize_inline_whitespace (src/utils.rs:18-33) for every record of a batch: each run of White_Space
  * characters becomes one ' ' and the result is trimmed.  The File and CSV sources apply it to every text

@@ -3224,6 +3224,12 @@ static int create_ctx(int device, hipStream_t stream, bool own, trp_ctx** out) {
 
 int trp_create(int device, trp_ctx** out) { return create_ctx(device, nullptr, true, out); }
 
+int trp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n < 0 ? 0 : n;
+}
+
 int trp_create_on_stream(int device, void* hip_stream, trp_ctx** out) {
     return create_ctx(device, (hipStream_t)hip_stream, false, out);
 }
@@ -4157,6 +4163,91 @@ int trp_preprocess_batch_select(trp_ctx* c, const uint8_t* bytes, const uint64_t
     if (rc) return rc;
     if (outputs & ~(TRP_OUT_ALL | TRP_OUT_CHUNK_TEXT)) return fail(TRP_E_ARG, "unknown output selector");
     return run_host(c, bytes, offsets, R, dc, out, outputs, chunk_text);
+}
+
+// ---- the steps after the path over host memory ------------------------------------------------------------
+// A packed host batch onto the device, run as one device batch (no pipelining: the text renderers work on the
+// last batch of the context, which must be the whole batch).
+static int stage_and_run(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
+                         trp_result* d) {
+    if (!c || !offsets) return fail(TRP_E_ARG, "null argument");
+    if (offsets[0] != 0) return fail(TRP_E_ARG, "offsets[0] must be 0");
+    const u64 N = offsets[R];
+    if (N && !bytes) return fail(TRP_E_ARG, "bytes is null");
+    if (N > TRP_MAX_BATCH_BYTES || R >= 0xFFFFFFFEull) return fail(TRP_E_TOO_LARGE, "batch too large: split it by record range");
+    for (u64 r = 0; r < R; r++)
+        if (offsets[r + 1] < offsets[r]) return fail(TRP_E_ARG, "offsets must be non-decreasing");
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->in_bytes.ensure(N + 64))) return rc;
+    if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
+    if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    return run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, d);
+}
+// Rendered texts (device) -> library-owned host arrays.
+static int texts_to_host(trp_ctx* c, const uint8_t* d_text, const uint64_t* d_off, uint64_t n, uint64_t nbytes,
+                         trp_chunk_text* out) {
+    memset(out, 0, sizeof(*out));
+    out->offsets = (uint64_t*)host_pool().alloc((n + 1) * sizeof(u64));
+    out->text = (uint8_t*)host_pool().alloc(nbytes ? nbytes : 1);
+    if (!out->offsets || !out->text) { trp_chunk_text_free(out); return fail(TRP_E_ARG, "out of host memory"); }
+    hipError_t e = hipMemcpyAsync(out->offsets, d_off, (n + 1) * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(out->text, d_text, nbytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { trp_chunk_text_free(out); return fail(TRP_E_HIP, std::string("copy of rendered texts: ") + hipGetErrorString(e)); }
+    out->n_bytes = nbytes;
+    return TRP_OK;
+}
+
+int trp_bm25_texts(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const uint64_t* doc_offsets,
+                   uint64_t n_docs, uint32_t max_tokens, const char* newline, trp_chunk_text* out) {
+    if (!out) return fail(TRP_E_ARG, "out is null");
+    memset(out, 0, sizeof(*out));
+    DevCfg dc = normalize_devcfg();   // the reference's default chunking; the text itself is passed through untouched
+    dc.denoise_enabled = 0;
+    dc.normalize = 0;
+    trp_result d;
+    int rc = stage_and_run(c, bytes, offsets, R, dc, &d);
+    if (rc) return rc;
+    uint8_t* d_text = nullptr;
+    uint64_t* d_off = nullptr;
+    uint64_t nbytes = 0;
+    if ((rc = trp_bm25_texts_device(c, doc_offsets, n_docs, max_tokens, newline, &d_text, &d_off, &nbytes))) return rc;
+    return texts_to_host(c, d_text, d_off, n_docs, nbytes, out);
+}
+
+int trp_head_tokens_text(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, uint32_t max_tokens,
+                         trp_chunk_text* out) {
+    if (!out) return fail(TRP_E_ARG, "out is null");
+    memset(out, 0, sizeof(*out));
+    DevCfg dc = normalize_devcfg();
+    dc.denoise_enabled = 0;
+    dc.normalize = 0;
+    trp_result d;
+    int rc = stage_and_run(c, bytes, offsets, R, dc, &d);
+    if (rc) return rc;
+    uint8_t* d_text = nullptr;
+    uint64_t* d_off = nullptr;
+    uint64_t nbytes = 0;
+    if ((rc = trp_head_tokens_text_device(c, max_tokens, &d_text, &d_off, &nbytes))) return rc;
+    return texts_to_host(c, d_text, d_off, R, nbytes, out);
+}
+
+int trp_chunk_bodies(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const trp_config* cfg,
+                     const uint32_t* chunk_index, const uint32_t* budget, uint64_t n, trp_chunk_text* out) {
+    if (!out) return fail(TRP_E_ARG, "out is null");
+    memset(out, 0, sizeof(*out));
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    trp_result d;
+    if ((rc = stage_and_run(c, bytes, offsets, R, dc, &d))) return rc;
+    uint8_t* d_text = nullptr;
+    uint64_t* d_off = nullptr;
+    uint64_t nbytes = 0;
+    if ((rc = trp_chunk_bodies_device(c, chunk_index, budget, n, &d_text, &d_off, &nbytes))) return rc;
+    return texts_to_host(c, d_text, d_off, n, nbytes, out);
 }
 
 void trp_chunk_text_free(trp_chunk_text* t) {

@@ -12,15 +12,19 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
+#include <deque>
 #include <exception>
 #include <map>
 #include <mutex>
+#include <memory>
 #include <optional>
 #include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -110,6 +114,15 @@ public:
     BatchResult(const BatchResult&) = delete;
     BatchResult& operator=(const BatchResult&) = delete;
     BatchResult(BatchResult&& o) noexcept : r_(o.r_), weight_(o.weight_) { std::memset(&o.r_, 0, sizeof o.r_); }
+    BatchResult& operator=(BatchResult&& o) noexcept {
+        if (this != &o) {
+            trp_result_free(&r_);
+            r_ = o.r_;
+            weight_ = o.weight_;
+            std::memset(&o.r_, 0, sizeof o.r_);
+        }
+        return *this;
+    }
 
     const trp_result& raw() const { return r_; }
     size_t records() const { return r_.n_records; }
@@ -204,6 +217,257 @@ private:
     Context& ctx_;
 };
 
+// One batch over several GPUs of this process: one Context and one host thread per entry of `devices` (HIP device
+// ordinals; an ordinal may be listed more than once).  The batch is cut into byte-balanced contiguous record
+// ranges, every shard runs the whole path on its own context at the same time as the others (records are
+// independent, src/chunking/algorithm.rs:7-13: nothing is exchanged between GPUs), and the result answers per
+// global record index.
+class ShardedResult {
+public:
+    size_t records() const { return first_.empty() ? 0 : first_.back(); }
+    size_t shards() const { return parts_.size(); }
+    const BatchResult& shard(size_t s) const { return parts_[s]; }
+    // (shard, record within the shard) of global record r
+    std::pair<size_t, size_t> locate(size_t r) const {
+        const size_t s = (size_t)(std::upper_bound(first_.begin(), first_.end(), r) - first_.begin()) - 1;
+        return {s, r - first_[s]};
+    }
+    bool dropped(size_t r) const { auto [s, i] = locate(r); return parts_[s].dropped(i); }
+    std::string_view text(size_t r) const { auto [s, i] = locate(r); return parts_[s].text(i); }
+    size_t token_count(size_t r) const { auto [s, i] = locate(r); return parts_[s].token_count(i); }
+    std::vector<RecordChunk> chunks(size_t r, const std::string& record_id, size_t section_idx) const {
+        auto [s, i] = locate(r);
+        return parts_[s].chunks(i, record_id, section_idx);
+    }
+
+private:
+    friend class ShardedPreprocessor;
+    std::vector<BatchResult> parts_;
+    std::vector<size_t> first_;   // first_[s] = first global record of shard s; one more entry: the record count
+};
+
+class ShardedPreprocessor {
+public:
+    explicit ShardedPreprocessor(const std::vector<int>& devices) {
+        if (devices.empty()) throw Error(TRP_E_ARG, "triplets_amd: ShardedPreprocessor needs at least one device");
+        for (int d : devices) ctxs_.emplace_back(new Context(d));
+    }
+    // every GPU the runtime shows
+    static std::vector<int> all_devices() {
+        std::vector<int> v;
+        for (int d = 0; d < trp_device_count(); d++) v.push_back(d);
+        return v;
+    }
+    size_t shards() const { return ctxs_.size(); }
+
+    ShardedResult run(const std::vector<std::string_view>& sections, const ChunkingStrategy& st) {
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> offs(1, 0);
+        for (auto s : sections) {
+            bytes.insert(bytes.end(), s.begin(), s.end());
+            offs.push_back(bytes.size());
+        }
+        return run_packed(bytes.data(), offs.data(), sections.size(), st);
+    }
+    ShardedResult run_packed(const uint8_t* bytes, const uint64_t* offsets, size_t n, const ChunkingStrategy& st) {
+        const size_t G = ctxs_.size();
+        ShardedResult out;
+        out.first_.assign(G + 1, n);
+        out.first_[0] = 0;
+        const uint64_t N = offsets[n];
+        for (size_t k = 1; k < G; k++) {   // shard k starts at the first record whose offset is >= k * N / G
+            const uint64_t target = (uint64_t)((unsigned __int128)N * k / G);
+            size_t r = (size_t)(std::lower_bound(offsets, offsets + n + 1, target) - offsets);
+            out.first_[k] = std::max(std::min(r, n), out.first_[k - 1]);
+        }
+        out.parts_.resize(G);
+        std::vector<std::exception_ptr> errs(G);
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < G; k++)
+            pool.emplace_back([&, k]() {
+                try {
+                    const size_t r0 = out.first_[k], r1 = out.first_[k + 1];
+                    std::vector<uint64_t> rebased(r1 - r0 + 1);
+                    for (size_t i = 0; i <= r1 - r0; i++) rebased[i] = offsets[r0 + i] - offsets[r0];
+                    BatchPreprocessor bp(*ctxs_[k]);
+                    out.parts_[k] = bp.run_packed(bytes + offsets[r0], rebased.data(), r1 - r0, st);
+                } catch (...) {
+                    errs[k] = std::current_exception();
+                }
+            });
+        for (auto& t : pool) t.join();
+        for (auto& e : errs)
+            if (e) std::rethrow_exception(e);
+        return out;
+    }
+
+private:
+    std::vector<std::unique_ptr<Context>> ctxs_;
+};
+
+// ---- the steps right after the path ----------------------------------------------------------------------
+namespace detail {
+inline std::vector<std::string> take_texts(trp_chunk_text& ct, size_t n) {
+    std::vector<std::string> out;
+    out.reserve(n);
+    for (size_t i = 0; i < n; i++)
+        out.emplace_back(reinterpret_cast<const char*>(ct.text) + ct.offsets[i], (size_t)(ct.offsets[i + 1] - ct.offsets[i]));
+    trp_chunk_text_free(&ct);
+    return out;
+}
+inline void pack(const std::vector<std::string_view>& texts, std::vector<uint8_t>& bytes, std::vector<uint64_t>& offs) {
+    offs.assign(1, 0);
+    for (auto s : texts) {
+        bytes.insert(bytes.end(), s.begin(), s.end());
+        offs.push_back(bytes.size());
+    }
+}
+}  // namespace detail
+
+// record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) for many records in one GPU batch: headings and
+// section texts in order, non-blank parts followed by the platform newline, cut to max_tokens tokens joined by one
+// space when there are more (0 = no limit), the record id when nothing is left.
+struct Bm25Section {
+    std::optional<std::string_view> heading;
+    std::string_view text;
+};
+struct Bm25Record {
+    std::string_view id;
+    std::vector<Bm25Section> sections;
+};
+inline std::vector<std::string> record_bm25_texts(Context& ctx, const std::vector<Bm25Record>& records, size_t max_tokens,
+                                                  const std::string& newline = "\n") {
+    std::vector<std::string_view> parts;
+    std::vector<uint64_t> doc(1, 0);
+    for (const auto& r : records) {
+        for (const auto& s : r.sections) {
+            if (s.heading) parts.push_back(*s.heading);
+            parts.push_back(s.text);
+        }
+        doc.push_back(parts.size());
+    }
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> offs;
+    detail::pack(parts, bytes, offs);
+    trp_chunk_text ct;
+    check(trp_bm25_texts(ctx.raw(), bytes.data(), offs.data(), parts.size(), doc.data(), records.size(),
+                         max_tokens > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_tokens, newline.c_str(), &ct));
+    auto out = detail::take_texts(ct, records.size());
+    for (size_t i = 0; i < out.size(); i++)
+        if (out[i].empty()) out[i] = std::string(records[i].id);   // bm25_backend.rs:517-519
+    return out;
+}
+// The BM25 query cap (bm25_backend.rs:219-225): every text cut to its first `limit` tokens joined by one space, or
+// left as it is when it has no more than that.
+inline std::vector<std::string> cap_tokens(Context& ctx, const std::vector<std::string_view>& texts, size_t limit) {
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> offs;
+    detail::pack(texts, bytes, offs);
+    trp_chunk_text ct;
+    check(trp_head_tokens_text(ctx.raw(), bytes.data(), offs.data(), texts.size(),
+                               limit > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)limit, &ct));
+    return detail::take_texts(ct, texts.size());
+}
+// Bodies of selected chunks of a batch cut to a token budget (the body half of decorate_chunk,
+// src/sampler/mod.rs:1497-1504): the sections are preprocessed and chunked with `st`, chunk chunk_index[i] of the
+// batch (in the batch's chunk order) is cut to budget[i] tokens, verbatim when the budget covers it.
+inline std::vector<std::string> chunk_bodies(Context& ctx, const std::vector<std::string_view>& sections,
+                                             const ChunkingStrategy& st, const std::vector<uint32_t>& chunk_index,
+                                             const std::vector<uint32_t>& budget) {
+    if (chunk_index.size() != budget.size()) throw Error(TRP_E_ARG, "triplets_amd: chunk_index and budget differ in length");
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> offs;
+    detail::pack(sections, bytes, offs);
+    auto ov = detail::overlaps_of(st);
+    trp_config c = detail::make_config(st, ov);
+    trp_chunk_text ct;
+    check(trp_chunk_bodies(ctx.raw(), bytes.data(), offs.data(), sections.size(), &c, chunk_index.data(), budget.data(),
+                           chunk_index.size(), &ct));
+    return detail::take_texts(ct, chunk_index.size());
+}
+// decorate_chunk (src/sampler/mod.rs:1470-1508; rng-free twin :1582-1620) for many chunks at once.  Every item is a
+// chunk's text and token count (RecordChunk::text / tokens_estimate) with the prefix the host's KvpPrefixSampler
+// produced for it (nullopt = the sampler gave none: the chunk is left as it is, :1481-1483).  Returns text and
+// tokens_estimate.
+struct DecorateItem {
+    std::string_view chunk_text;
+    std::optional<std::string_view> prefix;
+};
+struct Decorated {
+    std::string text;
+    size_t tokens_estimate;
+};
+inline std::vector<Decorated> decorate_chunks(Context& ctx, const std::vector<DecorateItem>& items, size_t max_window_tokens,
+                                              const std::string& newline = "\n") {
+    // one batch: the chunk texts, then the prefixes; token counts from the batch, cuts rendered on the GPU
+    const size_t n = items.size();
+    // (a prefix travels with one extra token behind it: a cut to at most its own token count is then always a real
+    // cut, rendered as tokens joined by one space - what :1490-1494 does even when nothing is dropped)
+    std::vector<std::string> guarded(n);
+    for (size_t i = 0; i < n; i++)
+        if (items[i].prefix) guarded[i] = std::string(*items[i].prefix) + " .";
+    std::vector<std::string_view> texts;
+    for (const auto& it : items) texts.push_back(it.chunk_text);
+    for (size_t i = 0; i < n; i++) texts.push_back(guarded[i]);
+    ChunkingStrategy plain;                       // no denoiser: the texts are tokenised as they are
+    plain.max_window_tokens = 0xFFFFFFFFull;      // one window per non-empty text: chunk k = k-th text with a token
+    plain.overlap_tokens = {0};
+    plain.summary_fallback_tokens = 0;
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> offs;
+    detail::pack(texts, bytes, offs);
+    auto ov = detail::overlaps_of(plain);
+    trp_config c = detail::make_config(plain, ov);
+    BatchResult counts;
+    {
+        BatchPreprocessor bp(ctx);
+        counts = bp.run_select(texts, plain, 0);   // per-record arrays only: token and chunk offsets
+    }
+    const trp_result& cr = counts.raw();
+    std::vector<uint32_t> index, budget;
+    std::vector<size_t> slot(n, (size_t)-1);   // which rendered text item i uses
+    const uint64_t mw = max_window_tokens;
+    std::vector<int> mode(n, 0);               // 0 unchanged, 1 prefix + body (maybe cut), 2 prefix tokens only
+    for (size_t i = 0; i < n; i++) {
+        if (!items[i].prefix) continue;                                      // :1481-1483
+        const uint64_t pt = counts.token_count(n + i) - 1, bt = counts.token_count(i), total = pt + bt;
+        if (mw > 0 && total > mw && pt >= mw) {                              // :1488-1495
+            mode[i] = 2;
+            slot[i] = index.size();
+            index.push_back((uint32_t)cr.chunk_offsets[n + i]);
+            budget.push_back((uint32_t)mw);
+        } else {
+            mode[i] = 1;
+            const bool cut = mw > 0 && total > mw;                           // :1496-1502
+            if (bt) {
+                slot[i] = index.size();
+                index.push_back((uint32_t)cr.chunk_offsets[i]);
+                budget.push_back(cut ? (uint32_t)(mw - pt) : 0xFFFFFFFFu);
+            }
+        }
+    }
+    std::vector<std::string> rendered;
+    if (!index.empty()) {
+        trp_chunk_text ct;
+        check(trp_chunk_bodies(ctx.raw(), bytes.data(), offs.data(), texts.size(), &c, index.data(), budget.data(), index.size(), &ct));
+        rendered = detail::take_texts(ct, index.size());
+    }
+    std::vector<Decorated> out(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t pt = items[i].prefix ? counts.token_count(n + i) - 1 : 0, bt = counts.token_count(i), total = pt + bt;
+        const std::string body = slot[i] != (size_t)-1 ? rendered[slot[i]] : std::string();
+        if (mode[i] == 0) out[i] = {std::string(items[i].chunk_text), (size_t)bt};
+        else if (mode[i] == 2) out[i] = {body, (size_t)mw};
+        else {
+            const bool cut = mw > 0 && total > mw;
+            // a body without a token is its own text (all whitespace or empty), as in the reference's format!
+            const std::string b = bt ? body : std::string(items[i].chunk_text);
+            out[i] = {std::string(*items[i].prefix) + newline + b, (size_t)(cut ? mw : total)};
+        }
+    }
+    return out;
+}
+
 // Per-call mirrors of the reference's public types (each call is a batch of one).
 class DenoiserPreprocessor {
 public:
@@ -282,6 +546,12 @@ private:
 // src/sampler/mod.rs:2510-2537), and tokenises the RAW text of every section when it refreshes its record
 // cache (record_has_long_anchor_or_context_section, src/sampler/mod.rs:1803-1812) - the place to call prefill.
 //
+// The reference's materialize is a pure function of the text it is handed (sliding_window.rs:18), and its record
+// cache is a rolling one (src/ingestion.rs:18).  Both hold here: an entry remembers the length and a 64-bit hash
+// of the text it was made from, a lookup with another text is a miss that replaces it (a record re-ingested under
+// its old id never gets its old chunks), and the table keeps at most `budget_bytes` of chunk text, dropping the
+// entries that were inserted first when it grows beyond that.  invalidate() drops a record by hand.
+//
 // Thread safety: every member may be called from any number of threads.  Lookups take a shared lock.  The GPU
 // context is used by one thread at a time; sections that miss the table while another thread is on the GPU
 // are queued and computed together, as one batch, by whichever thread gets the GPU next.
@@ -294,25 +564,29 @@ public:
         size_t section_idx;
         std::string_view text;
     };
-    explicit ChunkCache(Context& ctx) : ctx_(ctx) {}
+    static constexpr size_t DEFAULT_BUDGET = (size_t)1 << 30;
+    explicit ChunkCache(Context& ctx, size_t budget_bytes = DEFAULT_BUDGET) : ctx_(ctx), budget_(budget_bytes) {}
 
     // One batch for the chunks (with the strategy's denoiser, if any) and, when a denoiser is registered, one
     // pass-through batch over the same sections for the raw token counts.
     void prefill(const ChunkingStrategy& st, const std::vector<SectionRef>& sections) {
         std::lock_guard<std::mutex> gpu(gpu_mu_);
-        compute(st, sections);
+        compute(st, sections, nullptr);
     }
     // The chunks of one section (SlidingWindowChunker::materialize, sliding_window.rs:11-117).
     std::vector<RecordChunk> materialize(const ChunkingStrategy& st, const std::string& record_id, size_t section_idx,
                                          std::string_view section_text) {
         const Key key{strategy_hash(st), record_id, section_idx};
+        const uint64_t th = text_hash(section_text);
         {
             std::shared_lock<std::shared_mutex> rd(table_mu_);
             auto it = table_.find(key);
-            if (it != table_.end()) return it->second.chunks;
+            if (it != table_.end() && it->second.text_len == section_text.size() && it->second.text_hash == th)
+                return it->second.chunks;
         }
-        // miss: join the queue; the first thread to get the GPU computes everything queued for this strategy
-        Pending me{&st, SectionRef{record_id, section_idx, section_text}, key, false, nullptr};
+        // miss (or the text under this id has changed): join the queue; the first thread to get the GPU computes
+        // everything queued for this strategy
+        Pending me{&st, SectionRef{record_id, section_idx, section_text}, key, false, nullptr, {}};
         {
             std::lock_guard<std::mutex> q(queue_mu_);
             queue_.push_back(&me);
@@ -322,16 +596,15 @@ public:
             if (!me.done) drain();
         }
         if (me.error) std::rethrow_exception(me.error);
-        std::shared_lock<std::shared_mutex> rd(table_mu_);
-        return table_.at(key).chunks;
+        return std::move(me.result);   // handed over by the batch itself: the entry may already have been evicted
     }
     // WhitespaceTokenizer.token_count(&section.text) of the RAW section text - what the reference's sampler
-    // compares with max_window_tokens (src/sampler/mod.rs:1810) - for a section that was prefilled.
+    // compares with max_window_tokens (src/sampler/mod.rs:1810) - for a section that is in the table.
     std::optional<size_t> token_count(const std::string& record_id, size_t section_idx) const {
         std::shared_lock<std::shared_mutex> rd(table_mu_);
         auto it = raw_tokens_.find({record_id, section_idx});
         if (it == raw_tokens_.end()) return std::nullopt;
-        return it->second;
+        return it->second.tokens;
     }
     // Token count of the preprocessed text (what the windows of materialize are cut from).
     std::optional<size_t> preprocessed_token_count(const ChunkingStrategy& st, const std::string& record_id,
@@ -345,10 +618,29 @@ public:
         std::shared_lock<std::shared_mutex> rd(table_mu_);
         return table_.size();
     }
+    size_t bytes() const {   // what the budget is compared with: chunk text + record ids of the entries
+        std::shared_lock<std::shared_mutex> rd(table_mu_);
+        return bytes_;
+    }
+    size_t budget() const { return budget_; }
     void clear() {
         std::unique_lock<std::shared_mutex> wr(table_mu_);
         table_.clear();
         raw_tokens_.clear();
+        order_.clear();
+        bytes_ = 0;
+    }
+    // Drops every entry of one record (all sections, all strategies).  Returns the number of entries dropped.
+    size_t invalidate(const std::string& record_id) {
+        std::unique_lock<std::shared_mutex> wr(table_mu_);
+        size_t n = 0;
+        for (auto it = table_.begin(); it != table_.end();) {
+            if (it->first.record_id == record_id) { bytes_ -= it->second.cost; it = table_.erase(it); n++; }
+            else ++it;
+        }
+        for (auto it = raw_tokens_.lower_bound({record_id, 0}); it != raw_tokens_.end() && it->first.first == record_id;)
+            it = raw_tokens_.erase(it);
+        return n;
     }
     size_t gpu_batches() const { return batches_.load(); }   // batches run so far (for tests and tuning)
 
@@ -374,6 +666,22 @@ public:
         }
         return h;
     }
+    // 64-bit hash of a section text (eight bytes per step, FNV-style multiply, final avalanche).
+    static uint64_t text_hash(std::string_view t) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)t.size();
+        size_t i = 0;
+        for (; i + 8 <= t.size(); i += 8) {
+            uint64_t v;
+            std::memcpy(&v, t.data() + i, 8);
+            h = (h ^ v) * 0x100000001B3ull;
+            h ^= h >> 29;
+        }
+        uint64_t v = 0;
+        if (i < t.size()) std::memcpy(&v, t.data() + i, t.size() - i);
+        h = (h ^ v) * 0x100000001B3ull;
+        h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+        return h;
+    }
 
 private:
     struct Key {
@@ -387,6 +695,13 @@ private:
     struct Entry {
         std::vector<RecordChunk> chunks;
         size_t tokens = 0;
+        uint64_t text_hash = 0;
+        size_t text_len = 0;
+        size_t cost = 0;       // bytes counted against the budget
+        uint64_t serial = 0;   // insertion number (the rolling order)
+    };
+    struct RawCount {
+        size_t tokens;
     };
     struct Pending {
         const ChunkingStrategy* st;
@@ -394,6 +709,7 @@ private:
         Key key;
         bool done;
         std::exception_ptr error;
+        std::vector<RecordChunk> result;
     };
 
     // gpu_mu_ held.  Everything queued right now, one batch per strategy.
@@ -410,17 +726,29 @@ private:
             std::vector<SectionRef> refs;
             for (Pending* p : same) refs.push_back(p->ref);
             std::exception_ptr err;
+            std::vector<std::vector<RecordChunk>> made;
             try {
-                compute(*same.front()->st, refs);
+                compute(*same.front()->st, refs, &made);
             } catch (...) {
                 err = std::current_exception();
             }
-            for (Pending* p : same) { p->error = err; p->done = true; }
+            for (size_t i = 0; i < same.size(); i++) {
+                if (!err) same[i]->result = std::move(made[i]);
+                same[i]->error = err;
+                same[i]->done = true;
+            }
             work.swap(rest);
         }
     }
-    // gpu_mu_ held.
-    void compute(const ChunkingStrategy& st, const std::vector<SectionRef>& sections) {
+    static size_t cost_of(const Entry& e, const std::string& record_id) {
+        size_t n = sizeof(Entry) + record_id.size();
+        for (const auto& c : e.chunks) n += sizeof(RecordChunk) + c.text.size() + c.record_id.size();
+        return n;
+    }
+    // gpu_mu_ held.  `handed` (optional) receives a copy of every section's chunks.
+    void compute(const ChunkingStrategy& st, const std::vector<SectionRef>& sections,
+                 std::vector<std::vector<RecordChunk>>* handed) {
+        if (handed) handed->assign(sections.size(), {});
         if (sections.empty()) return;
         std::vector<std::string_view> texts;
         texts.reserve(sections.size());
@@ -443,20 +771,49 @@ private:
         for (size_t i = 0; i < sections.size(); i++) {
             made[i].chunks = r.chunks(i, sections[i].record_id, sections[i].section_idx);
             made[i].tokens = r.token_count(i);
+            made[i].text_hash = text_hash(sections[i].text);
+            made[i].text_len = sections[i].text.size();
+            made[i].cost = cost_of(made[i], sections[i].record_id);
+            if (handed) (*handed)[i] = made[i].chunks;
         }
         std::unique_lock<std::shared_mutex> wr(table_mu_);
         for (size_t i = 0; i < sections.size(); i++) {
-            table_[Key{h, sections[i].record_id, sections[i].section_idx}] = std::move(made[i]);
-            raw_tokens_[{sections[i].record_id, sections[i].section_idx}] = raw[i];
+            Key key{h, sections[i].record_id, sections[i].section_idx};
+            auto it = table_.find(key);
+            if (it != table_.end()) { bytes_ -= it->second.cost; table_.erase(it); }
+            made[i].serial = ++serial_;
+            bytes_ += made[i].cost;
+            order_.emplace_back(made[i].serial, key);
+            table_.emplace(std::move(key), std::move(made[i]));
+            raw_tokens_[{sections[i].record_id, sections[i].section_idx}] = RawCount{raw[i]};
+        }
+        // the rolling part: the oldest entries go while the table is over its budget (the newest one always stays)
+        while (bytes_ > budget_ && order_.size() > 1) {
+            auto [serial, key] = std::move(order_.front());
+            order_.pop_front();
+            auto it = table_.find(key);
+            if (it == table_.end() || it->second.serial != serial) continue;   // replaced or invalidated meanwhile
+            bytes_ -= it->second.cost;
+            table_.erase(it);
+            raw_tokens_.erase({key.record_id, key.section_idx});   // the raw count goes with the entry: both are re-made by a miss
+        }
+        while (!order_.empty()) {   // forget order entries whose table entry is gone
+            auto it = table_.find(order_.front().second);
+            if (it != table_.end() && it->second.serial == order_.front().first) break;
+            order_.pop_front();
         }
     }
 
     Context& ctx_;
+    size_t budget_;
     mutable std::shared_mutex table_mu_;
     std::mutex gpu_mu_, queue_mu_;
     std::vector<Pending*> queue_;
     std::map<Key, Entry> table_;
-    std::map<std::pair<std::string, size_t>, size_t> raw_tokens_;
+    std::map<std::pair<std::string, size_t>, RawCount> raw_tokens_;
+    std::deque<std::pair<uint64_t, Key>> order_;
+    size_t bytes_ = 0;
+    uint64_t serial_ = 0;
     std::atomic<size_t> batches_{0};
 };
 

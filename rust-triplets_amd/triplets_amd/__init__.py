@@ -79,7 +79,7 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
            "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
            "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event", "trp_chunk_bodies_device", "trp_bm25_texts_device", "trp_preprocess_batch_select",
-           "trp_chunk_text_free", "trp_token_bound", "trp_preprocess_batch_device_noalloc"]
+           "trp_chunk_text_free", "trp_token_bound", "trp_preprocess_batch_device_noalloc", "trp_device_count", "trp_bm25_texts", "trp_chunk_bodies", "trp_head_tokens_text"]
 
 _lib = None
 
@@ -101,6 +101,8 @@ def load_library():
                                % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     L.trp_last_error.restype = C.c_char_p
+    L.trp_device_count.restype = C.c_int
+    L.trp_device_count.argtypes = []
     L.trp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.trp_create_on_stream.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.trp_wait_event.argtypes = [C.c_void_p, C.c_void_p]
@@ -141,6 +143,11 @@ def load_library():
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.trp_bm25_texts_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.trp_bm25_texts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                 C.c_char_p, C.POINTER(_ChunkText)]
+    L.trp_head_tokens_text.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(_ChunkText)]
+    L.trp_chunk_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Config), C.c_void_p,
+                                   C.c_void_p, C.c_uint64, C.POINTER(_ChunkText)]
     L.trp_normalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Result)]
     L.trp_normalize_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                              C.POINTER(_Result)]
@@ -344,6 +351,15 @@ class Context:
             _check(L.trp_create_on_stream(device, C.c_void_p(int(stream)), C.byref(h)))
         self._h = h
         self._L = L
+        self.device = int(device)
+        self._helper: Optional["Context"] = None
+
+    def helper(self) -> "Context":
+        """A second context on the same GPU, created on first use and kept: for small side batches (prefixes,
+        BM25 documents) that must not replace this context's last device batch."""
+        if self._helper is None:
+            self._helper = Context(self.device)
+        return self._helper
 
     def wait_event(self, hip_event: int) -> None:
         """Work enqueued by later calls waits for the given hipEvent_t (e.g. a recorded
@@ -351,6 +367,9 @@ class Context:
         _check(self._L.trp_wait_event(self._h, C.c_void_p(int(hip_event))))
 
     def close(self):
+        if getattr(self, "_helper", None) is not None:
+            self._helper.close()
+            self._helper = None
         if self._h:
             self._L.trp_destroy(self._h)
             self._h = None
@@ -502,6 +521,53 @@ class Context:
                                                C.byref(o), C.byref(n)))
         return self._texts_to_host(t.value or 0, o.value or 0, int(n.value), len(idx))
 
+    def _host_texts(self, ct, n) -> List[bytes]:
+        """trp_chunk_text in host memory -> list of n byte strings (and release it)."""
+        try:
+            offs = np.frombuffer(C.string_at(ct.offsets, (n + 1) * 8), dtype=np.uint64)
+            text = C.string_at(ct.text, int(ct.n_bytes)) if ct.n_bytes else b""
+            return [text[int(offs[i]):int(offs[i + 1])] for i in range(n)]
+        finally:
+            self._L.trp_chunk_text_free(C.byref(ct))
+
+    def bm25_texts_host(self, data: np.ndarray, offsets: np.ndarray, doc_offsets: Sequence[int], max_tokens: int,
+                        newline: str = "\n") -> List[bytes]:
+        """record_bm25_text (bm25_backend.rs:503-532) over a packed host batch whose records are the headings and
+        section texts of the documents in order: document i is records [doc_offsets[i], doc_offsets[i+1])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        do = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        ct = _ChunkText()
+        _check(self._L.trp_bm25_texts(self._h, data.ctypes.data if data.size else None, offsets.ctypes.data,
+                                      len(offsets) - 1, do.ctypes.data, len(do) - 1, int(max_tokens), newline.encode(),
+                                      C.byref(ct)))
+        return self._host_texts(ct, len(do) - 1)
+
+    def head_tokens_text_host(self, data: np.ndarray, offsets: np.ndarray, max_tokens: int) -> List[bytes]:
+        """Every record of a packed host batch cut to its first max_tokens tokens (verbatim when it has no more):
+        the BM25 query cap, bm25_backend.rs:219-225, with max_tokens = 64."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ct = _ChunkText()
+        _check(self._L.trp_head_tokens_text(self._h, data.ctypes.data if data.size else None, offsets.ctypes.data,
+                                            len(offsets) - 1, int(max_tokens), C.byref(ct)))
+        return self._host_texts(ct, len(offsets) - 1)
+
+    def chunk_bodies_host(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
+                          strategy: ChunkingStrategy, chunk_index: Sequence[int], budget: Sequence[int]) -> List[bytes]:
+        """The packed host batch preprocessed and chunked as by preprocess_batch, then chunk chunk_index[i] cut to
+        budget[i] tokens (the body of a decorated chunk, src/sampler/mod.rs:1497-1504), all in one call."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        idx = np.ascontiguousarray(chunk_index, dtype=np.uint32)
+        bud = np.ascontiguousarray(budget, dtype=np.uint32)
+        cfg = _make_cfg(denoiser, strategy)
+        ct = _ChunkText()
+        _check(self._L.trp_chunk_bodies(self._h, data.ctypes.data if data.size else None, offsets.ctypes.data,
+                                        len(offsets) - 1, C.byref(cfg), idx.ctypes.data, bud.ctypes.data, len(idx),
+                                        C.byref(ct)))
+        return self._host_texts(ct, len(idx))
+
     def bm25_texts(self, doc_offsets: Sequence[int], max_tokens: int, newline: str = "\n") -> List[bytes]:
         """record_bm25_text (bm25_backend.rs:503-532) of the documents whose parts (headings and section texts,
         in order) are records [doc_offsets[i], doc_offsets[i+1]) of the last device batch.  A document
@@ -519,6 +585,89 @@ class Context:
         arr = (_KernelTime * 64)()
         n = _check(self._L.trp_get_profile(self._h, arr, 64))
         return [(arr[i].name.decode(), float(arr[i].ms)) for i in range(min(n, 64))]
+
+
+class ShardedPreprocessor:
+    """One batch over several GPUs of this process: one context and one host thread per entry of `devices`
+    (HIP device ordinals; an ordinal may be listed more than once, which gives that GPU several shards).  The
+    batch is cut into byte-balanced record ranges (shard_ranges), every shard runs the whole path on its own
+    context at the same time as the others (records are independent: nothing is exchanged between GPUs) and the
+    results are concatenated in record order (concat_results: offset shifts only)."""
+
+    def __init__(self, devices: Sequence[int]):
+        if not len(devices):
+            raise TripletsAmdError("ShardedPreprocessor needs at least one device")
+        self.devices = [int(d) for d in devices]
+        self._ctxs: List[Context] = []
+        try:
+            for d in self.devices:
+                self._ctxs.append(Context(d))
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        for c in self._ctxs:
+            c.close()
+        self._ctxs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _run(self, data, offsets, call) -> BatchResult:
+        import threading
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ranges = shard_ranges(offsets, len(self._ctxs))
+        parts: List[Optional[BatchResult]] = [None] * len(ranges)
+        errors: List[Optional[BaseException]] = [None] * len(ranges)
+
+        def work(i):
+            try:
+                r0, r1 = ranges[i]
+                sub, so = shard_slice(data, offsets, r0, r1)
+                parts[i] = call(self._ctxs[i], sub, so)
+            except BaseException as e:   # re-raised in the caller's thread
+                errors[i] = e
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(ranges))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        return concat_results(parts)
+
+    def preprocess_batch(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
+                         strategy: ChunkingStrategy) -> BatchResult:
+        """Context.preprocess_batch over all devices.  tok_start of the result is u64 (the concatenated text of
+        several shards may exceed the limit of one batch)."""
+        return self._run(data, offsets, lambda c, d, o: c.preprocess_batch(d, o, denoiser, strategy))
+
+    def normalize_batch(self, data: np.ndarray, offsets: np.ndarray) -> BatchResult:
+        return self._run(data, offsets, lambda c, d, o: c.normalize_batch(d, o))
+
+
+def preprocess_sharded(data: np.ndarray, offsets: np.ndarray, devices: Sequence[int],
+                       denoiser: DenoiserConfig = None, strategy: ChunkingStrategy = None) -> BatchResult:
+    """One packed host batch sharded by record range over `devices` (see ShardedPreprocessor, which keeps its
+    contexts between batches; this convenience creates and destroys them per call)."""
+    with ShardedPreprocessor(devices) as sp:
+        return sp.preprocess_batch(data, offsets, denoiser or DenoiserConfig(), strategy or ChunkingStrategy())
+
+
+def visible_devices() -> int:
+    """Number of GPUs the HIP runtime shows to this process (0 without the runtime or a GPU)."""
+    try:
+        L = load_library()
+    except (TripletsAmdError, OSError):
+        return 0
+    return max(0, int(L.trp_device_count()))
 
 
 _default_ctx: Optional[Context] = None
@@ -659,14 +808,9 @@ def decorate_chunks(ctx: Context, chunks: np.ndarray, chunk_index: Sequence[int]
     the prefix the host's KvpPrefixSampler produced for it: returns [(text, tokens_estimate)].
     `chunks` is the batch's chunk descriptor array on the host.  The prefixes are tokenised on the GPU as a
     batch of their own (on prefix_ctx, so that ctx keeps its batch); the bodies are cut on the GPU."""
-    own = prefix_ctx is None
-    pctx = prefix_ctx or Context(0)
-    try:
-        pdata, poffs = pack(list(prefixes))
-        pres = pctx.preprocess_batch(pdata, poffs, DenoiserConfig(False), ChunkingStrategy())
-    finally:
-        if own:
-            pctx.close()
+    pctx = prefix_ctx or ctx.helper()   # same GPU as ctx; kept with it, not created per call
+    pdata, poffs = pack(list(prefixes))
+    pres = pctx.preprocess_batch(pdata, poffs, DenoiserConfig(False), ChunkingStrategy())
     n = len(prefixes)
     np_tok = np.diff(pres.tok_offsets.astype(np.int64))
     sel = chunks[np.asarray(chunk_index, dtype=np.int64)]
@@ -690,9 +834,9 @@ def decorate_chunks(ctx: Context, chunks: np.ndarray, chunk_index: Sequence[int]
 
 
 def record_bm25_texts(records, max_tokens: int, newline: str = "\n", ctx: Context = None) -> List[bytes]:
-    """record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) for many records at once.
-    records: [(record_id, [(heading or None, text), ...]), ...] with byte strings."""
-    import torch
+    """record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) for many records at once, on ctx's GPU
+    (the default context's when none is given).  records: [(record_id, [(heading or None, text), ...]), ...] with
+    byte strings.  The batch runs on ctx's helper context, so ctx keeps its own last device batch."""
     ctx = ctx or default_context()
     parts, doc_offsets = [], [0]
     for _, sections in records:
@@ -702,14 +846,5 @@ def record_bm25_texts(records, max_tokens: int, newline: str = "\n", ctx: Contex
             parts.append(text)
         doc_offsets.append(len(parts))
     data, offs = pack(parts)
-    stream = torch.cuda.current_stream().cuda_stream
-    own = Context(0, stream=stream)
-    try:
-        db = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).cuda()
-        do = torch.from_numpy(offs.astype(np.int64)).cuda()
-        own.preprocess_batch_device(db.data_ptr(), do.data_ptr(), len(parts), len(data), DenoiserConfig(False),
-                                    ChunkingStrategy())
-        texts = own.bm25_texts(doc_offsets, max_tokens, newline)
-    finally:
-        own.close()
+    texts = ctx.helper().bm25_texts_host(data, offs, doc_offsets, max_tokens, newline)
     return [t if t else rid for t, (rid, _) in zip(texts, records)]       # :517-519

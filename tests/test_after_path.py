@@ -103,6 +103,14 @@ def test_gpu_decorate_chunks_match_the_oracle():
                 for i, c in enumerate(sel):
                     want = O.decorate_chunk(exp.chunk_text(c), prefixes[i], window, nl)
                     assert got[i] == want, (enabled, window, c, prefixes[i])
+        # the host-memory entry point (trp_chunk_bodies: batch + bodies in one call) gives the same bodies as the
+        # device one on the resident batch
+        budgets = [rng.choice([0, 1, 3, 7, 0xFFFFFFFF]) for _ in sel]
+        den_h, st_h = T.DenoiserConfig(enabled, 0.35, True), T.ChunkingStrategy(mwt, list(ov), 0.35, sft)
+        assert ctx.helper().chunk_bodies_host(data, offs, den_h, st_h, sel, budgets) == ctx.chunk_bodies(sel, budgets)
+        for i in range(0, len(sel), 37):
+            if 0 < budgets[i] < 0xFFFFFFFF:
+                assert ctx.chunk_bodies([sel[i]], [budgets[i]])[0] == O.cap_tokens(exp.chunk_text(sel[i]), budgets[i])
         # the reference's own cases through the device path
         one = recs.index(b"one two three")
         c_one = int(exp.chunk_offsets[one])
@@ -152,4 +160,5 @@ def test_gpu_record_bm25_texts_match_the_oracle():
                                 T.ChunkingStrategy())
     t, o, n = ctx.head_tokens_text(q["limit"])
     assert ctx._texts_to_host(t, o, n, len(texts)) == [O.cap_tokens(x, q["limit"]) for x in texts]
+    assert ctx.head_tokens_text_host(data, offs, q["limit"]) == [O.cap_tokens(x, q["limit"]) for x in texts]
     ctx.close()

@@ -104,3 +104,67 @@ def test_gpu_shards_equal_unsharded_call():
             parts.append(ctx.preprocess_batch(d, o, den, st))
         assert_same(exp, T.concat_results(parts), recs, "gpu shards g=%d" % g)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_in_process_sharded_host_api():
+    """preprocess_sharded / ShardedPreprocessor: one thread and one context per listed device, all at once.  A box
+    with one GPU lists it four times: four contexts and four host threads run their shards concurrently."""
+    recs = textgen.corpus(23, 2500)
+    recs.append(("x1 " * 9000 + "\n" + "12 34 ab 56 " * 3000).encode())   # one record far longer than a shard
+    data, offs = O.pack(recs)
+    from test_normalize import oracle_normalize
+    den, st = T.DenoiserConfig(True, 0.35, True), T.ChunkingStrategy(40, [8, 3], 0.35, 10)
+    exp = O.batch(data, offs, O.make_config(True, 0.35, True, 40, (8, 3), 10))
+    assert T.visible_devices() >= 1
+    got = T.preprocess_sharded(data, offs, [0] * 4, den, st)
+    assert_same(exp, got, recs, "preprocess_sharded over [0]*4")
+    with T.ShardedPreprocessor([0, 0, 0]) as sp:
+        for seed in (24, 25):   # the contexts are reused from batch to batch
+            r2 = textgen.corpus(seed, 700)
+            d2, o2 = O.pack(r2)
+            assert_same(O.batch(d2, o2, O.make_config(True, 0.35, True, 40, (8, 3), 10)),
+                        sp.preprocess_batch(d2, o2, den, st), r2, "ShardedPreprocessor seed %d" % seed)
+        nrm = sp.normalize_batch(data, offs)
+        assert nrm.n_records == len(recs)
+        for r in (0, 17, len(recs) - 1):
+            assert nrm.record_text(r) == oracle_normalize(recs[r])
+    # more shards than records, and an empty batch
+    few = recs[:2]
+    d3, o3 = O.pack(few)
+    assert_same(O.batch(d3, o3, O.make_config(True, 0.35, True, 40, (8, 3), 10)),
+                T.preprocess_sharded(d3, o3, [0] * 5, den, st), few, "five shards, two records")
+    with pytest.raises(T.TripletsAmdError):
+        T.preprocess_sharded(data, offs, [T.visible_devices() + 7], den, st)   # no such GPU: no silent fallback
+
+
+# ---- bench.py's own launcher (python bench.py --gpus N without torch.distributed.run) ---------------------
+def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
+    """bench.launch_ranks starts N fresh processes with the environment torch.distributed.run would give them:
+    here two CPU ranks (gloo) that each run the oracle over their own record range and reassemble the batch."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    out = tmp_path / "rank0.txt"
+    rc = bench.launch_ranks(2, [sys.executable, os.path.join(HERE, "launch_child.py"), str(out)], timeout=180)
+    assert rc == 0
+    assert out.read_text().strip() == "ok world=2"
+    # a failing rank fails the launch (and the other rank is stopped, not left waiting)
+    rc = bench.launch_ranks(2, [sys.executable, os.path.join(HERE, "launch_child.py"), str(out), "fail1"], timeout=180)
+    assert rc != 0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` where fewer than two GPUs are visible must fail with a clear message instead of
+    reporting a smaller run."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two or more GPUs visible")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRP_BENCH_DEVICE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2" in p.stderr and "visible" in p.stderr
+    assert "n_gpus" not in p.stdout
