@@ -1085,9 +1085,9 @@ struct G3Masks {
 // the position of the line's first byte in the view and corpus_end the position where the corpus ends (or ~0
 // when that is outside the view).  Returns false when the line does not fit (its end is not in the view, or
 // it is longer than 64 * W bytes).
-template <int W>
+template <int W, class RT>
 __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool rab, u32 n_words, u32 corpus_end,
-                                     float max_ratio) {
+                                     const RT& rt) {
     const u32 w0 = s >> 6;
     u32 e = 0xFFFFFFFFu;
     for (u32 w = w0; w <= w0 + W && w < n_words; w++) {   // the next line start, if it is close enough
@@ -1111,7 +1111,7 @@ __device__ inline bool g3_lane_solve(const G3Masks& a, u32 s, bool table, bool r
             }
             return r;
         },
-        s, e, max_ratio, K, KS);
+        s, e, rt, K, KS);
     bool first = true;
 #pragma unroll
     for (u32 j = 0; j <= (u32)W; j++) {
@@ -1165,6 +1165,12 @@ struct PlanShared {
     u64 g3base;
     u32 red[3][NT / 64];
     RsShared rs;
+    uint16_t thr1[RATIO_TAB];   // the digit-ratio test as a table (RatioTab)
+};
+static_assert(RATIO_TAB == NT, "one table entry per thread of k_plan");
+// The table of the digit-ratio test as a kernel argument (filled on the host, ratio_table_fill).
+struct RatioArg {
+    uint16_t thr1[RATIO_TAB];
 };
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 
@@ -1172,7 +1178,7 @@ template <bool NORMALIZE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
                                               const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
                                               const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
-                                              PlanMem plan, u64* __restrict__ g3list, u64 g3cap,
+                                              RatioArg ratio, PlanMem plan, u64* __restrict__ g3list, u64 g3cap,
                                               u64* __restrict__ g3count,
                                               u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
                                               u32* __restrict__ tile_flags, u32 stop_after) {
@@ -1187,9 +1193,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         tile_load(bytes, N, tS, regs);
         rs_fetch(offsets, rec_lo, R, t, rf);
         stage_tables(uni);
+        if (!NORMALIZE) sh.thr1[tid] = ratio.thr1[tid];
         tile_store(regs, sh.tile.bytes);
         rs_store(rf, offsets, rec_lo, R, N, t, sh.rs);
     }
+    const RatioTab rt = {cfg.max_digit_ratio, sh.thr1};
     // what enters the tile from its neighbours: the same address for every lane, loaded into scalar registers
     const J seed_j = seedJ[t];
     const S seed_s = seedS[t];
@@ -1236,7 +1244,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (stop_after == 3) { if (k.ci.d == 0x12345678u) g3list[0] = k.co.d + k.ci.a + (k.ci_rab ? 1 : 0); return; }
     bool head_g3 = false;   // the line that runs into this block is a digit-heavy line (marked at its first byte)
     Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
-                        : plan_block(L.c, L.d, k, cfg, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3, false);
+                        : plan_block(L.c, L.d, k, cfg, rt, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3, false);
     if (!NORMALIZE) {
         const u64 sp_nl = sh.tokc[tid];
         plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, L.d.V);
@@ -1278,7 +1286,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
                 const u32 ent = sh.list[i], s0 = ent & 0x3FFFu;
                 // lines of more than 128 bytes are left for k_gate3_solve
                 if (g3_lane_solve<G3_SHORT>(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
-                                  tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, cfg.max_digit_ratio))
+                                  tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, rt))
                     atomicAnd(reinterpret_cast<unsigned long long*>(&sh.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
             }
             __syncthreads();
@@ -1488,6 +1496,13 @@ __device__ inline WaveBits<W> g3b_orn(const WaveBits<W>& a, const WaveBits<W>& b
     WaveBits<W> r;
 #pragma unroll
     for (int j = 0; j < W; j++) r.w[j] = a.w[j] | ~b.w[j];
+    return r;
+}
+template <int W>
+__device__ inline WaveBits<W> g3b_xnor(const WaveBits<W>& a, const WaveBits<W>& b) {
+    WaveBits<W> r;
+#pragma unroll
+    for (int j = 0; j < W; j++) r.w[j] = ~(a.w[j] ^ b.w[j]);
     return r;
 }
 template <int W>
@@ -1706,7 +1721,8 @@ __device__ inline bool g3_wave_line(const u8* __restrict__ bytes, const u64* __r
         const u64 m = below((int)b) & ~below((int)a);
         X.w[j] &= m; DG.w[j] &= m; AL.w[j] &= m;
     }
-    const WaveBits<W> K = g3_bits_solve(X, DG, AL, cfg.max_digit_ratio);
+    const RatioDiv rt = {cfg.max_digit_ratio};
+    const WaveBits<W> K = g3_bits_solve(X, DG, AL, rt);
     const WaveBits<W> KS = g3b_run_starts(K);   // kept tokens are whole tokens: the runs of K
     int first_j = -1;
 #pragma unroll
@@ -2065,7 +2081,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         if (have && j == 0) {
             const u64 view0 = w0 * 64;
             const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
-            const bool ok = g3_lane_solve<G3_WORDS>(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, cfg.max_digit_ratio);
+            const RatioDiv rt = {cfg.max_digit_ratio};
+            const bool ok = g3_lane_solve<G3_WORDS>(gm, (u32)(p & 63), table, rab, G3_VIEW, cend, rt);
             const u64 mb = ~(1ull << (p & 63));   // the marker's flag bits
             atomicAnd(reinterpret_cast<unsigned long long*>(&plan.px[w0].PSP), mb);
             atomicAnd(reinterpret_cast<unsigned long long*>(&plan.px[w0].PNL), mb);
@@ -3048,6 +3065,10 @@ struct trp_ctx {
     DevBuf sel;                         // caller's selection arrays (chunk indices + budgets, document offsets)
     u64* h_totals = nullptr;            // pinned
     unsigned char* scratch_ptr = nullptr;   // this GPU's copy of the fixed scratch array (see scratch_of_device)
+    // the digit-ratio test as a table (ratio_table_fill), kept for the max_digit_ratio it was made for
+    RatioArg ratio_arg = {};
+    u32 ratio_bits = 0;
+    bool ratio_valid = false;
     bool profiling = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
     std::vector<trp_kernel_time> last_profile;
@@ -3332,6 +3353,15 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
     u64* totals = B.totals;
     const PlanMem plan = plan_view(B.plan, nB);
     J* SA = B.SA;
+    if (!pass && !dc.normalize) {
+        u32 bits;
+        memcpy(&bits, &dc.max_digit_ratio, 4);
+        if (!c->ratio_valid || c->ratio_bits != bits) {
+            ratio_table_fill(dc.max_digit_ratio, c->ratio_arg.thr1);
+            c->ratio_bits = bits;
+            c->ratio_valid = true;
+        }
+    }
     {
         Prof pr(c, "k_rec_lo");   // also clears the totals and counters
         hipLaunchKernelGGL(k_rec_lo, dim3((unsigned)((R + 1 + 255) / 256)), dim3(256), 0, st, d_offsets, R, N, nT, nW, rec_lo,
@@ -3366,11 +3396,11 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
             { Prof pr(c, "k_plan");
               if (dc.normalize)
                   hipLaunchKernelGGL(k_plan<true>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
-                                     B.seedJ, B.seedS, dc, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
+                                     B.seedJ, B.seedS, dc, c->ratio_arg, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
                                      ttoks, tflags, c->plan_stop());
               else
                   hipLaunchKernelGGL(k_plan<false>, dim3((unsigned)nT), dim3(NT), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB,
-                                     B.seedJ, B.seedS, dc, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
+                                     B.seedJ, B.seedS, dc, c->ratio_arg, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
                                      ttoks, tflags, c->plan_stop()); }
             { Prof pr(c, "k_gate3");
               hipLaunchKernelGGL(k_gate3_solve, dim3(4096), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,

@@ -812,6 +812,32 @@ TRP_HD bool ratio_exceeds64(u64 d, u64 a, float max_ratio) {
     return r > max_ratio;
 }
 
+// The same test through a table: for a given total t = digits + alpha the f32 quotient digits / t grows with the
+// number of digits, so "digits / t > max" is "digits >= thr1[t]", thr1[t] being the smallest number of digits that
+// exceeds (t + 1 when none does).  The table covers the totals below RATIO_TAB (lines of ordinary length) and is
+// filled on the host with the very division it replaces; larger totals take the division.
+constexpr u32 RATIO_TAB = 256;
+inline void ratio_table_fill(float max_ratio, uint16_t* thr1) {
+    for (u32 t = 0; t < RATIO_TAB; t++) {
+        u32 d = 0;
+        while (d <= t && !ratio_exceeds(d, t - d, max_ratio)) d++;
+        thr1[t] = (uint16_t)d;
+    }
+}
+struct RatioTab {
+    float max;
+    const uint16_t* thr1;   // RATIO_TAB entries (LDS on the device)
+    TRP_HD bool exceeds(u32 d, u32 a) const {
+        const u32 t = d + a;
+        if (t < RATIO_TAB) return d >= (u32)thr1[t];
+        return ratio_exceeds(d, a, max);
+    }
+};
+struct RatioDiv {   // no table at hand: always the division
+    float max;
+    TRP_HD bool exceeds(u32 d, u32 a) const { return ratio_exceeds(d, a, max); }
+};
+
 // ---- the emit plan -----------------------------------------------------------------------------------
 // Four bit planes per block.  C: the byte is copied.  TOK: the byte belongs to a token of the output
 // (copied and not whitespace).  PSP / PNL: one ' ' / '\n' is emitted in front of the (copied) byte.
@@ -886,24 +912,82 @@ TRP_HD LaneCarry carry_from(const J& P, const S& X, bool next_rs) {
     return k;
 }
 
+// Segmented "seen before": bit i of the result is the OR of x over the positions j < i of the same segment, a
+// segment beginning at every set bit of `starts`; c0 is the value that enters bit 0 (ignored when bit 0 starts a
+// segment).  One addition: with K = positions whose successor starts a segment, the operands X = ~K and Y = x & ~K
+// generate a carry at every x, pass a carry on everywhere else and kill it in front of a segment start, and the
+// carry into each position is what was asked for.
+TRP_HD u64 seen_before(u64 x, u64 starts, bool c0) {
+    const u64 K = starts >> 1;
+    const u64 X = ~K, Y = x & ~K;
+    const u64 sum = X + Y + ((c0 && !(starts & 1ull)) ? 1ull : 0ull);
+    return sum ^ X ^ Y;
+}
+
 // own_head / own_tail: the block's own statistics before its first and from its last line start on, as
 // lane_J computes them (head and tail of the block's summary).
 // *head_g3 (optional): the line that runs into the block from an earlier one is a digit-heavy line; it is
 // marked in the block that holds its first byte, nothing of it is planned here.
 // fold = false leaves plan_fold_prefixes() to the caller.
-TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg, const LineSum& own_head,
-                       const LineSum& own_tail, bool* head_g3 = nullptr, bool fold = true) {
-    Plan out = {0, 0, 0, 0};
-    bool head_pending = false;
+// The gates (denoiser_preprocessor.rs:228-262) are decided line by line - drop (no alphabetic character), table
+// row, digit-heavy, plain - and collected as masks of the lines' bytes; the plan then follows from the masks for
+// all lines of the block at once.
+template <class RT>
+TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg, const RT& rt,
+                       const LineSum& own_head, const LineSum& own_tail, bool* head_g3 = nullptr, bool fold = true) {
+    const bool has_ls = d.LS != 0;
     const bool head0 = !(d.LS & 1ull);      // the block starts inside a line begun earlier
-    // Cell trimming of table rows (strip_table_pipes): a whitespace byte survives only when the
-    // nearest non-whitespace byte on either side, within the line, is text (not a pipe).  The masks are
-    // only needed by blocks that hold (part of) a table row and are computed on first use.
-    u64 T = 0, IW = 0, CS = 0;
-    bool have_table_masks = false;
-    auto table_masks = [&]() {
-        T = d.LC & ~c.ws & ~c.pipe;         // text bytes
-        const u64 W = d.LC & c.ws;          // whitespace inside lines
+    const int first_ls = has_ls ? ctz(d.LS) : 64, last_ls = has_ls ? top(d.LS) : 0;
+    const u64 empty = d.TERM | d.DEL;
+    // bytes of the plain lines / of the table rows that are kept; first bytes of the digit-heavy lines that start
+    // in the block, and which of those are table rows
+    u64 PLm = 0, TBm = 0, G3S = 0, G3T = 0;
+    bool head_pending = false;
+    auto verdict = [&](u32 dd, u32 aa, u32 pp, bool first_pipe, u64 R, u64 sbit, bool is_head) {
+        const bool keep = aa != 0;                                   // gate 2
+        const bool table = cfg.strip_markdown && first_pipe && pp >= 2u;
+        const bool heavy = keep && rt.exceeds(dd, aa);               // gate 3
+        const bool plain = keep && !heavy && !table, tbl = keep && !heavy && table;
+        PLm |= plain ? R : 0ull;
+        TBm |= tbl ? R : 0ull;
+        G3S |= heavy ? sbit : 0ull;
+        G3T |= (heavy && table) ? sbit : 0ull;
+        if (is_head && heavy) head_pending = true;
+    };
+    // The line that runs into the block and the block's last line take their own part from the block's
+    // summary; the lines in between (they start and end inside the block) are counted here.  Empty lines (a
+    // line start that sits on its own terminator) are skipped: nothing of them is ever emitted.
+    if (head0) {
+        LineSum tot = ls_add(k.ci, own_head);
+        if (!has_ls) tot = ls_add(tot, k.co);
+        verdict(tot.d, tot.a, tot.p, ls_first(tot) == 1u, below(first_ls) & d.V, 0ull, true);
+    }
+    if (has_ls && !((empty >> last_ls) & 1ull)) {
+        const LineSum tot = ls_add(own_tail, k.co);
+        verdict(tot.d, tot.a, tot.p, ls_first(tot) == 1u, ~below(last_ls) & d.V, bit(last_ls), false);
+    }
+    u64 todo = has_ls ? (d.LS & ~empty & ~bit(last_ls)) : 0ull;
+    while (todo) {
+        const u64 sb = todo & (0ull - todo);                 // the line's first byte
+        todo ^= sb;
+        const u64 above = d.LS & ~(sb | (sb - 1ull));        // a later line start exists
+        const u64 R = (above & (0ull - above)) - sb;         // [s, next line start)
+        const u64 nw = R & ~c.ws;                            // (terminators are whitespace)
+        verdict((u32)popc(c.dig & R), (u32)popc(c.alp & R), (u32)popc(c.pipe & R),
+                (c.pipe & nw & (0ull - nw)) != 0, R, sb, false);
+    }
+    Plan out;
+    // the record has an alphabetic character (hence a kept line) before this byte
+    const u64 FA = seen_before(c.alp & d.V, d.RS, k.ar_in);
+    out.C = d.LC & PLm;
+    out.TOK = (d.LC & PLm & ~c.ws) | G3S;
+    out.PSP = G3T;
+    out.PNL = ((PLm & d.LS) | G3S) & FA;
+    if (TBm) {
+        // Cell trimming of table rows (strip_table_pipes): a whitespace byte survives only when the nearest
+        // non-whitespace byte on either side, within the line, is text (not a pipe).
+        const u64 T = d.LC & ~c.ws & ~c.pipe;     // text bytes
+        const u64 W = d.LC & c.ws;                // whitespace inside lines
         const u64 cin_text = (head0 && ls_last(k.ci) == 2u) ? 1ull : 0ull;
         const u64 Wp = W & ~d.LS;
         const u64 SL = ((T << 1) | cin_text) & Wp;
@@ -912,76 +996,27 @@ TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const
         const u64 cin_right = (ls_first(k.co) == 2u) ? bit(63) : 0ull;
         const u64 SR = ((T >> 1) | cin_right) & Wq;
         const u64 rW = brev(Wq), rS = brev(SR);
-        const u64 RT = brev(rW & ~(rW + rS));
-        IW = LT & RT;
+        const u64 RT2 = brev(rW & ~(rW + rS));
+        const u64 IW = LT & RT2;
         const u64 prevtext = (((T | LT) << 1) | cin_text) & ~d.LS;
-        CS = T & ~prevtext;                 // first byte of a trimmed cell
-        have_table_masks = true;
-    };
-    // One line of the block: bytes [s, e) of it, `tot` the statistics of the whole line.
-    auto line = [&](int s, u64 R, bool is_head, const LineSum& tot) {
-        if (tot.a == 0) return;             // gate 2: no alphabetic character, the line is dropped
-        bool rab;
-        if (is_head) rab = k.ci_rab;
-        else {
-            u64 rsb = d.RS & below(s + 1);
-            if (rsb) rab = (c.alp & below(s) & ~below(top(rsb))) != 0;
-            else rab = k.ar_in || (c.alp & below(s)) != 0;
-        }
-        bool table = cfg.strip_markdown && ls_first(tot) == 1u && tot.p >= 2u;
-        bool g3 = ratio_exceeds(tot.d, tot.a, cfg.max_digit_ratio);
-        if (g3) {
-            if (!is_head) {
-                out.TOK |= bit(s);
-                if (table) out.PSP |= bit(s);
-                if (rab) out.PNL |= bit(s);
-            } else head_pending = true;
-        } else if (!table) {
-            out.C |= d.LC & R;
-            out.TOK |= d.LC & R & ~c.ws;
-            if (!is_head && rab) out.PNL |= bit(s);
-        } else {
-            if (!have_table_masks) table_masks();
-            out.C |= R & (T | IW);
-            out.TOK |= R & T;
-            u64 cs = CS & R, Tr = T & R;
-            if (Tr) {
-                u64 first = Tr & (~Tr + 1ull);
-                if (is_head && ls_seen_text(k.ci)) out.PSP |= cs;
-                else {
-                    out.PSP |= cs & ~first;
-                    if (rab && (cs & first)) out.PNL |= first;
-                }
-            }
-        }
-    };
-    // The line that runs into the block and the block's last line take their own part from the block's
-    // summary; the lines in between (they start and end inside the block) are counted here.  Empty lines (a
-    // line start that sits on its own terminator) are skipped: nothing of them is ever emitted.
-    const bool has_ls = d.LS != 0;
-    const int first_ls = has_ls ? ctz(d.LS) : 64, last_ls = has_ls ? top(d.LS) : 0;
-    const u64 empty = d.TERM | d.DEL;
-    if (head0) {
-        LineSum tot = ls_add(k.ci, own_head);
-        if (!has_ls) tot = ls_add(tot, k.co);
-        line(0, below(first_ls) & d.V, true, tot);
-    }
-    if (has_ls && !((empty >> last_ls) & 1ull))
-        line(last_ls, ~below(last_ls) & d.V, false, ls_add(own_tail, k.co));
-    u64 todo = has_ls ? (d.LS & ~empty & ~bit(last_ls)) : 0ull;
-    while (todo) {
-        const int s = ctz(todo);
-        todo &= todo - 1;
-        const u64 R = below(ctz(d.LS & ~below(s + 1))) & ~below(s);   // a later line start exists
-        line(s, R, false, range_sum(c, d, R));
+        const u64 CS = T & ~prevtext & TBm;       // first bytes of the trimmed cells of the kept rows
+        // the first text byte of every line (of a line that runs in: only when it had no text before the block);
+        // no byte of a line before its first text byte is alphabetic, so FA there is the line's own "the record
+        // has a kept line before this one"
+        const u64 FT = T & ~seen_before(T, d.LS, head0 && ls_seen_text(k.ci));
+        out.C |= TBm & (T | IW);
+        out.TOK |= TBm & T;
+        out.PSP |= CS & ~FT;
+        out.PNL |= CS & FT & FA;
     }
     if (fold) plan_fold_prefixes(out, c.sp, c.nl, d.V);
     if (head_g3) *head_g3 = head_pending;
     return out;
 }
-TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg) {
+template <class RT>
+TRP_HD Plan plan_block(const Cls& c, const Derived& d, const LaneCarry& k, const DevCfg& cfg, const RT& rt) {
     const J own = lane_J(c, d);
-    return plan_block(c, d, k, cfg, own.head, own.tail);
+    return plan_block(c, d, k, cfg, rt, own.head, own.tail);
 }
 
 // Plan of the pass-through configuration (denoiser disabled): every byte is "copied" in place and
@@ -1273,6 +1308,13 @@ TRP_HD G3BitsT<W> g3b_or(const G3BitsT<W>& a, const G3BitsT<W>& b) {
     return r;
 }
 template <int W>
+TRP_HD G3BitsT<W> g3b_xnor(const G3BitsT<W>& a, const G3BitsT<W>& b) {   // ~(a ^ b)
+    G3BitsT<W> r;
+    TRP_UNROLL
+    for (int j = 0; j < W; j++) r.w[j] = ~(a.w[j] ^ b.w[j]);
+    return r;
+}
+template <int W>
 TRP_HD G3BitsT<W> g3b_orn(const G3BitsT<W>& a, const G3BitsT<W>& b) {   // a | ~b
     G3BitsT<W> r;
     TRP_UNROLL
@@ -1334,8 +1376,8 @@ TRP_HD void g3b_opaque(G3BitsT<W>& x) {
 // the line's tokens; DG / AL: its ASCII digits / alphabetic characters (one bit per character).
 // V is a bit vector type with the g3b_* operations: G3BitsT<W> (a line in the registers of one lane), or a
 // vector spread over the lanes of a wavefront.
-template <class V>
-TRP_HD V g3_bits_solve(V X, const V& DG, const V& AL, float max_ratio) {
+template <class V, class RT>
+TRP_HD V g3_bits_solve(V X, const V& DG, const V& AL, const RT& rt) {
     // seed: the tokens with a letter.  P = the first letter of each such token (the carry from the token
     // start runs through the letterless bytes Y and stops on a letter or on the separator after the token)
     V K;
@@ -1348,20 +1390,21 @@ TRP_HD V g3_bits_solve(V X, const V& DG, const V& AL, float max_ratio) {
     u32 d0 = g3b_popc_and(DG, K);
     for (;;) {
         g3b_opaque(X);
-        // Z: kept bytes and everything that is not a token; a carry from a kept token's first (last) byte
-        // stops on the first (last) byte of the next (previous) token that is not kept.  The kept tokens
-        // are the runs of K.
-        const V Z = g3b_orn(K, X);
-        const V NS = g3b_andn(g3b_add(Z, g3b_run_starts(K)), Z);
+        // Z: kept bytes and everything that is not a token (K is made of whole tokens of X, so K | ~X is the
+        // complement of X ^ K).  Adding K to Z sends a carry up from every kept token through the rest of its run
+        // of Z - the token itself, the separators after it, further kept tokens - onto the first byte of the next
+        // token that is not kept; the mirror image finds the last byte of the previous one.
+        const V Z = g3b_xnor(X, K);
+        const V NS = g3b_andn(g3b_add(Z, K), Z);
         V Wv = g3b_run_from(X, NS);
         {
             const V rZ = g3b_rev(Z);
-            const V rPE = g3b_andn(g3b_add(rZ, g3b_rev(g3b_run_ends(K))), rZ);
+            const V rPE = g3b_andn(g3b_add(rZ, g3b_rev(K)), rZ);
             Wv = g3b_or(Wv, g3b_rev(g3b_run_from(g3b_rev(X), rPE)));
         }
         if (!g3b_any(Wv)) break;
         const u32 wd = g3b_popc_and(DG, Wv);
-        if (ratio_exceeds(d0 + wd, a0, max_ratio)) break;
+        if (rt.exceeds(d0 + wd, a0)) break;
         d0 += wd;
         K = g3b_or(K, Wv);
     }
@@ -1376,8 +1419,8 @@ TRP_HD V g3_bits_solve(V X, const V& DG, const V& AL, float max_ratio) {
 struct G3Src {
     u64 x, dg, al;
 };
-template <int W, class F>
-TRP_HD void g3_solve_shifted(F src, u32 s, u32 e, float max_ratio, u64 (&K)[W + 1], u64 (&KS)[W + 1]) {
+template <int W, class F, class RT>
+TRP_HD void g3_solve_shifted(F src, u32 s, u32 e, const RT& rt, u64 (&K)[W + 1], u64 (&KS)[W + 1]) {
     const u32 w0 = s >> 6, len = e - s;
     const int o = (int)(s & 63u);
     G3BitsT<W> X, DG, AL;
@@ -1392,7 +1435,7 @@ TRP_HD void g3_solve_shifted(F src, u32 s, u32 e, float max_ratio, u64 (&K)[W + 
         AL.w[j] = (o ? (cur.al >> o) | (nx.al << (64 - o)) : cur.al) & m;
         cur = nx;
     }
-    const G3BitsT<W> Kb = g3_bits_solve(X, DG, AL, max_ratio);
+    const G3BitsT<W> Kb = g3_bits_solve(X, DG, AL, rt);
     const G3BitsT<W> Sb = g3b_run_starts(Kb);   // kept tokens are whole tokens: the runs of Kb
     TRP_UNROLL
     for (int j = 0; j <= W; j++) {

@@ -138,6 +138,10 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
     }
 
     if (cfg.denoise_enabled) {
+        // the digit-ratio test through its table, as on the device
+        uint16_t thr1[RATIO_TAB];
+        ratio_table_fill(cfg.max_digit_ratio, thr1);
+        const RatioTab rt = {cfg.max_digit_ratio, thr1};
         std::vector<Derived> der(nB);
         std::vector<J> jl(nB);
         std::vector<u64> spm(nB, 0);
@@ -219,7 +223,7 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                     bool prev_tok = p > 0 && !rs_at(p) && !byte_is_ws(PlainBlk{base + p}, -1);
                     plan[b] = plan_normalize(cls[b], der[b], k.ar_in, prev_tok, spm[b]);
                 } else {
-                    plan[b] = plan_block(cls[b], der[b], k, cfg);
+                    plan[b] = plan_block(cls[b], der[b], k, cfg, rt);
                 }
                 pre = j_combine(pre, jl[b]);
             }
@@ -261,10 +265,10 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                     const u32 s0 = (u32)(p & 63), e0 = (u32)(e - w0 * 64);
                     if (e - p <= 64u * G3_SHORT) {
                         u64 K2[G3_SHORT + 1], S2[G3_SHORT + 1];
-                        g3_solve_shifted<G3_SHORT>(masks, s0, e0, cfg.max_digit_ratio, K2, S2);
+                        g3_solve_shifted<G3_SHORT>(masks, s0, e0, rt, K2, S2);
                         for (int i = 0; i <= G3_SHORT; i++) { Kw[i] = K2[i]; KSw[i] = S2[i]; }
                     } else {
-                        g3_solve_shifted<G3_WORDS>(masks, s0, e0, cfg.max_digit_ratio, Kw, KSw);
+                        g3_solve_shifted<G3_WORDS>(masks, s0, e0, rt, Kw, KSw);
                     }
                     for (u64 q = p; q < e; q++) {
                         const u64 i = q - w0 * 64;

@@ -100,6 +100,17 @@ def load_library():
         raise TripletsAmdError("HIP library not built: %s is missing (run __graft_entry__.build())"
                                % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    if os.environ.get("TRIPLETS_AMD_LIB"):
+        # an older build under test may lack the newest entry points: they then fail when called, not here
+        class _Missing:
+            def __init__(self, name):
+                self.name = name
+
+            def __call__(self, *a):
+                raise TripletsAmdError("%s is not exported by %s" % (self.name, LIB_PATH))
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                setattr(L, name, _Missing(name))
     L.trp_last_error.restype = C.c_char_p
     L.trp_device_count.restype = C.c_int
     L.trp_device_count.argtypes = []
