@@ -626,6 +626,8 @@ struct WaveNeighbours {
     template <class B>
     __device__ u32 next_planes3(u32 mine, const B&) const { return from_next_lane(mine); }
     __device__ u32 swap_spill(u32 v) const { return from_prev_lane(v); }
+    template <class B>
+    __device__ bool leftover(const B&, u64, u64, const UniTables&, u64*, u64*) const { return false; }
 };
 
 // Lanes that hold consecutive blocks in groups (the windows of k_seed): the caller says whether the lanes next
@@ -638,6 +640,67 @@ struct WindowNeighbours {
     template <class B>
     __device__ u32 next_planes3(u32 mine, const B&) const { return from_next_lane(mine); }
     __device__ u32 swap_spill(u32 v) const { return from_prev_lane(v); }
+    template <class B>
+    __device__ bool leftover(const B&, u64, u64, const UniTables&, u64*, u64*) const { return false; }
+};
+
+// ---- multi-byte characters handed out over the lanes --------------------------------------------------------
+// Characters outside the bit-plane rules of classify_leads_planes (the less common scripts) would be decoded and
+// looked up one after the other by the lane that owns them, the whole wavefront waiting for the lane with the
+// most.  Instead the positions of the wave's unsettled lead bytes are listed, lane k decodes and looks up the k-th
+// of them (64 at a time), and the results go back to the owning blocks through per-block masks in LDS.
+constexpr u32 MB_LIST = 256;
+struct MbScratch {
+    u64 alp[64];                // lead bytes of the alphabetic characters of each block
+    u64 ws[64];                 // bytes of the whitespace characters of each block
+    uint16_t list[MB_LIST];     // block << 6 | byte of every listed lead byte of the wave, in order
+};
+// The lanes of a wavefront, lane i with block i of the wave's 64, sharing a scratch area.
+struct WaveHandOut {
+    MbScratch* ms;
+    __device__ bool any(bool x) const { return __ballot(x) != 0; }
+    __device__ bool has_next() const { return (threadIdx.x & 63) < 63; }
+    __device__ bool has_prev() const { return (threadIdx.x & 63) > 0; }
+    template <class B>
+    __device__ u32 next_planes3(u32 mine, const B&) const { return from_next_lane(mine); }
+    __device__ u32 swap_spill(u32 v) const { return from_prev_lane(v); }
+    __device__ bool leftover(const PadBlk& blk, u64 lead, u64 V, const UniTables& ut, u64* ws, u64* alp) const {
+        const int lane = threadIdx.x & 63;
+        const u32 n = (u32)popc(lead);
+        // uniform: with at most two characters in any lane the lanes are done sooner on their own (about 45
+        // instructions per character there; listing, two synchronisations and a round here)
+        if (__ballot(n > 2u) == 0) return false;
+        const u32 inc = wave_incl_scan_add(n);
+        const u32 M = readlane_u32(inc, 63);
+        if (M > MB_LIST) return false;            // uniform: too many for the list, every lane takes its own
+        ms->alp[lane] = 0;
+        ms->ws[lane] = 0;
+        u32 at = inc - n;
+        for (u32 m = (u32)lead; m; m &= m - 1) ms->list[at++] = (uint16_t)((u32)(lane << 6) | (u32)__builtin_ctz(m));
+        for (u32 m = (u32)(lead >> 32); m; m &= m - 1)
+            ms->list[at++] = (uint16_t)((u32)(lane << 6) | 32u | (u32)__builtin_ctz(m));
+        wave_lds_sync();
+        const PadBlk wblk = {blk.p - lane * PAD_STRIDE};   // the wave's 64 blocks (and what follows) as one run of bytes
+        for (u32 s0 = 0; s0 < M; s0 += 64) {   // uniform
+            const u32 slot = s0 + (u32)lane;
+            if (slot < M) {
+                const u32 pos = ms->list[slot], ob = pos >> 6, bp = pos & 63u;
+                const int k = classify_lead_at(wblk, (int)pos, ut);
+                if (k > 0) {
+                    atomicOr(reinterpret_cast<unsigned long long*>(&ms->alp[ob]), 1ull << bp);
+                } else if (k < 0) {   // a whitespace character marks all its bytes, in the next block too
+                    const u64 m = k == -2 ? 3ull : 7ull;
+                    atomicOr(reinterpret_cast<unsigned long long*>(&ms->ws[ob]), m << bp);
+                    if (bp > 61u && ob < 63u && (m >> (64u - bp)))
+                        atomicOr(reinterpret_cast<unsigned long long*>(&ms->ws[ob + 1]), m >> (64u - bp));
+                }
+            }
+        }
+        wave_lds_sync();
+        *alp |= ms->alp[lane];
+        *ws |= ms->ws[lane] & V;
+        return true;
+    }
 };
 
 struct LaneCtx {
@@ -651,8 +714,10 @@ struct LaneCtx {
 };
 
 // rs_words: record-start words of the tile's blocks (RsShared), complete before the call.
+// mb: per-wavefront scratch for handing out the characters the bit-plane rules leave open (WaveHandOut); nullptr:
+// every lane decodes its own.
 __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, u64 N, u64 tS, bool want_lines,
-                                     const u64* rs_words, bool normalize = false) {
+                                     const u64* rs_words, bool normalize = false, MbScratch* mb = nullptr) {
     LaneCtx L;
     const int tid = threadIdx.x;
     const PadBlk blk = lane_block(sh, tid);
@@ -663,8 +728,13 @@ __device__ inline LaneCtx lane_setup(const TileShared& sh, const UniTables& ut, 
         L.c = z;
         L.nl = 0;
     } else {
-        WaveNeighbours nb;   // every lane of the wavefront is here, lane i with block i of its 64
-        L.c = classify_block_fast(blk, L.nvalid, ut, nb);
+        if (mb) {
+            WaveHandOut nb = {mb};
+            L.c = classify_block_fast(blk, L.nvalid, ut, nb);
+        } else {
+            WaveNeighbours nb;   // every lane of the wavefront is here, lane i with block i of its 64
+            L.c = classify_block_fast(blk, L.nvalid, ut, nb);
+        }
         L.sp = L.c.sp;
         L.nl = L.c.nl;
     }
@@ -1154,12 +1224,18 @@ __host__ __device__ inline PlanMem plan_view(void* base, u64 nB) {
     return m;
 }
 
-struct PlanShared {
-    TileShared tile;   // byte image; after classification reused for the eight G3Masks arrays
-    J jscan[NT / 64];
+struct PlanWork {
     u64 tokc[TILE_BLOCKS];
     u64 marks[TILE_BLOCKS];
     uint16_t list[G3_LCAP];
+};
+struct PlanShared {
+    TileShared tile;   // byte image; after classification reused for the eight G3Masks arrays
+    J jscan[NT / 64];
+    union {            // the classifier's per-wave scratch is dead before the first of the others is written
+        PlanWork w;
+        MbScratch mb[NT / 64];
+    };
     u32 scan32[NT / 64];
     u32 nlist;
     u64 g3base;
@@ -1173,6 +1249,7 @@ struct RatioArg {
     uint16_t thr1[RATIO_TAB];
 };
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
+static_assert(sizeof(MbScratch) * (NT / 64) <= sizeof(PlanWork), "the classifier's scratch must fit under the planning arrays");
 
 template <bool NORMALIZE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
@@ -1203,14 +1280,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const S seed_s = seedS[t];
     __syncthreads();
     if (stop_after == 1) return;   // profiling aid (see trp_ctx::plan_stop): end after the named phase
-    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w, NORMALIZE);
+    LaneCtx L = lane_setup(sh.tile, lds_tables(uni), N, tS, true, sh.rs.w, NORMALIZE, &sh.mb[wave]);
+    // (the classifier's scratch shares its space with the arrays written from here on: every wave is through with
+    // it when it gets here, and the first of those arrays that another wave reads is read after the next barrier)
     if (stop_after == 2) { if (L.c.ws == 0x123456789ull) g3list[0] = L.d.LS ^ L.c.alp ^ L.c.dig; return; }
     // The ' ' and '\n' bytes are needed once more, at the very end (plan_fold_prefixes): parked in LDS in one
     // mask until then.  A '\n' is a terminator and a ' ' is line content, which tells them apart again.
-    if (!NORMALIZE) sh.tokc[tid] = L.c.sp | L.c.nl;
+    // Parked in the middle of the lane's own block of the byte image: nobody else reads those bytes (neighbours
+    // look at most three bytes into a block, from either side), and the planning arrays still hold other
+    // wavefronts' classifier scratch until the next barrier.
+    u32* const park = reinterpret_cast<u32*>(sh.tile.bytes + (tid + 1) * PAD_STRIDE + 16);
+    if (!NORMALIZE) { const u64 v = L.c.sp | L.c.nl; park[0] = (u32)v; park[1] = (u32)(v >> 32); }
     const J own = lane_J(L.c, L.d);
     // the block's own head / tail statistics are used again by plan_block: parked in one register each
     const u32 own_head = pack_ls(own.head), own_tail = pack_ls(own.tail);
+#ifdef TRP_FINE_STOPS
+    if (stop_after == 21) { if (own_head == 0x12345678u) g3list[0] = own_tail + own.g; return; }
+#endif
     WaveLines W;
     NearLines Q = {};
     wave_ballots(own, W);
@@ -1226,6 +1312,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
         if (lane == 0) sh.jscan[wave] = wt;
     }
+#ifdef TRP_FINE_STOPS
+    if (stop_after == 22) { if (Q.ci == 0x12345678u) g3list[0] = Q.co + W.lsm; return; }
+#endif
     __syncthreads();   // also: every lane has classified its block, the byte image is free from here on
     // what enters this wave from the left and from the right: folds over the other waves' totals.  The
     // summaries are the same for every lane: moved to scalar registers, so that the folds run on the scalar unit
@@ -1245,8 +1334,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     bool head_g3 = false;   // the line that runs into this block is a digit-heavy line (marked at its first byte)
     Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
                         : plan_block(L.c, L.d, k, cfg, rt, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3, false);
+    u64 sp_nl = 0;
     if (!NORMALIZE) {
-        const u64 sp_nl = sh.tokc[tid];
+        sp_nl = (u64)park[0] | ((u64)park[1] << 32);
         plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, L.d.V);
     }
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
@@ -1270,27 +1360,74 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         gm.ws[tid] = L.c.ws; gm.pipe[tid] = L.c.pipe; gm.dig[tid] = L.c.dig; gm.alp[tid] = L.c.alp;
         gm.ls[tid] = L.d.LS;
         gm.G[tid] = 0; gm.gPSP[tid] = 0; gm.gPNL[tid] = 0;
-        sh.marks[tid] = marks;
-        u32 nm = popc(marks), tot = 0;
-        u32 at = block_scan_excl_fwd(nm, U32Add(), 0u, 0u, sh.scan32, &tot);   // ends with a barrier
-        if (tot > 0) {   // uniform
-            for (u64 m = marks; m && at < G3_LCAP; m &= m - 1, at++) {
-                int jb = ctz(m);
-                sh.list[at] = (uint16_t)((u32)(tid * BLOCK + jb) | (((pl.PSP >> jb) & 1ull) ? 0x4000u : 0u) |
-                                    (((pl.PNL >> jb) & 1ull) ? 0x8000u : 0u));
+        sh.w.marks[tid] = marks;
+        sh.w.tokc[tid] = sp_nl;   // (the byte image, where it was parked, now holds the mask arrays)
+        // Two work lists: lines that end within 64 bytes of their first byte (more than half of the digit-heavy
+        // lines of OCR text) are solved with masks of one word, the others with two words, at twice the price per
+        // operation.  A marker below the block's last line start belongs to a line that ends inside the block; the
+        // line of the last line start is short when the next block has a line start no further in than the marker
+        // is in this block (the last lane of a wavefront cannot tell and says "long", which is always right).
+        const u32 nls_lo = from_next_lane((u32)L.d.LS), nls_hi = from_next_lane((u32)(L.d.LS >> 32));
+        u64 shortm = 0;
+        if (marks) {
+            const int last = top(L.d.LS);   // markers are line starts
+            const u64 next_ls = (u64)nls_lo | ((u64)nls_hi << 32);
+            shortm = marks & below(last);
+            if (((marks >> last) & 1ull) && (next_ls & below(last + 1))) shortm |= bit(last);
+        }
+        const u64 longm = marks & ~shortm;
+        // positions in the two lists: one packed prefix sum (short | long << 16) over the tile
+        const u32 cnt2 = (u32)popc(shortm) | ((u32)popc(longm) << 16);
+        const u32 inc2 = wave_incl_scan_add(cnt2);
+        if (lane == 63) sh.scan32[wave] = inc2;
+        __syncthreads();   // also: the mask arrays are complete
+        u32 pre2 = 0, tot2 = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+            const u32 tw = sh.scan32[w];
+            if (w < wave) pre2 += tw;
+            tot2 += tw;
+        }
+        if (tot2 > 0) {   // uniform
+            uint16_t* list_s = sh.w.list;
+            uint16_t* list_l = sh.w.list + G3_LCAP / 2;
+            u32 at_s = (pre2 + inc2 - cnt2) & 0xFFFFu, at_l = (pre2 + inc2 - cnt2) >> 16;
+            // a tile whose lines all fit one pass of the two-word solver takes that one pass
+            const bool one_list = (tot2 & 0xFFFFu) + (tot2 >> 16) <= 64u;   // uniform
+            if (one_list) { at_l += at_s; shortm = 0; }
+            for (u64 m = marks; m; m &= m - 1) {
+                const int jb = ctz(m);
+                const uint16_t ent = (uint16_t)((u32)(tid * BLOCK + jb) | (((pl.PSP >> jb) & 1ull) ? 0x4000u : 0u) |
+                                                (((pl.PNL >> jb) & 1ull) ? 0x8000u : 0u));
+                if ((shortm >> jb) & 1ull) { if (at_s < G3_LCAP / 2) list_s[at_s] = ent; at_s++; }
+                else { if (at_l < G3_LCAP / 2) list_l[at_l] = ent; at_l++; }
             }
             __syncthreads();
-            const u32 nl = tot < G3_LCAP ? tot : G3_LCAP;
+#ifdef TRP_FINE_STOPS
+            if (stop_after == 51) return;
+#endif
+            const u32 n_s = one_list ? 0u : min(tot2 & 0xFFFFu, G3_LCAP / 2);
+            const u32 n_l = one_list ? (tot2 & 0xFFFFu) + (tot2 >> 16) : min(tot2 >> 16, G3_LCAP / 2);
             const u32 tile_valid = (u32)(N - tS < (u64)TILE ? N - tS : (u64)TILE);
-            for (u32 i = tid; i < nl; i += NT) {   // one line per lane
-                const u32 ent = sh.list[i], s0 = ent & 0x3FFFu;
+            const u32 cend = tS + TILE >= N ? tile_valid : 0xFFFFFFFFu;
+            // one line per lane; the short list is handed out from the first lane of the workgroup upwards, the
+            // long one from the last lane downwards, so that the two usually occupy different wavefronts
+            for (u32 i = tid; i < n_s; i += NT) {
+                const u32 ent = list_s[i], s0 = ent & 0x3FFFu;
+                if (g3_lane_solve<1>(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS, cend, rt))
+                    atomicAnd(reinterpret_cast<unsigned long long*>(&sh.w.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
+            }
+            for (u32 i = NT - 1 - tid; i < n_l; i += NT) {
+                const u32 ent = list_l[i], s0 = ent & 0x3FFFu;
                 // lines of more than 128 bytes are left for k_gate3_solve
-                if (g3_lane_solve<G3_SHORT>(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS,
-                                  tS + TILE >= N ? tile_valid : 0xFFFFFFFFu, rt))
-                    atomicAnd(reinterpret_cast<unsigned long long*>(&sh.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
+                if (g3_lane_solve<G3_SHORT>(gm, s0, (ent >> 14) & 1u, (ent >> 15) & 1u, TILE_BLOCKS, cend, rt))
+                    atomicAnd(reinterpret_cast<unsigned long long*>(&sh.w.marks[s0 >> 6]), ~(1ull << (s0 & 63u)));
             }
             __syncthreads();
-            const u64 left = sh.marks[tid];
+#ifdef TRP_FINE_STOPS
+            if (stop_after == 52) return;
+#endif
+            const u64 left = sh.w.marks[tid];
             const u64 solved = marks & ~left;
             pl.PSP = (pl.PSP & ~solved) | gm.gPSP[tid];
             pl.PNL = (pl.PNL & ~solved) | gm.gPNL[tid];
@@ -1298,8 +1435,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
             pl.TOK |= gm.G[tid];
             marks = left;
             {   // the separators of the kept tokens
-                const u64 sp_nl = sh.tokc[tid];
-                plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, below(L.nvalid));
+                const u64 sn = sh.w.tokc[tid];
+                plan_fold_prefixes(pl, sn & L.d.LC, sn & ~L.d.LC, below(L.nvalid));
             }
         }
     }

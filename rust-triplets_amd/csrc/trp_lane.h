@@ -419,6 +419,9 @@ TRP_HD u32 classify_leads_planes(const u32 (&p)[8], const Q& q, u32 lead, u32* a
 //                     three bytes of the next block as pack_planes3() packs them (mine = this block's own)
 //   has_prev()        the previous block belongs to the group; swap_spill(v) hands v to the next block and
 //                     returns what the previous block handed over (0 without one)
+//   leftover(...)     the group classifies the lead bytes its blocks could not settle by rule (every block of the
+//                     group calls it, with its own lead bytes) and ORs the results into *ws / *alp; false: the
+//                     group has no way to do so and every block decodes its own
 struct NoNeighbours {
     TRP_HD bool any(bool x) const { return x; }
     TRP_HD bool has_next() const { return false; }
@@ -426,6 +429,8 @@ struct NoNeighbours {
     template <class B>
     TRP_HD u32 next_planes3(u32, const B&) const { return 0; }
     TRP_HD u32 swap_spill(u32) const { return 0; }
+    template <class B>
+    TRP_HD bool leftover(const B&, u64, u64, const UniTables&, u64*, u64*) const { return false; }
 };
 // Blocks classified one after the other in ascending order (host code): the planes of the next block are built
 // from its first three bytes, the spill is kept from one call to the next.
@@ -447,16 +452,83 @@ struct SeqNeighbours {
         kept = v;
         return r;
     }
+    template <class B>
+    bool leftover(const B&, u64, u64, const UniTables&, u64*, u64*) const { return false; }
 };
 
+// One multi-byte character by its lead byte q[j] (11xxxxxx): straight-line decode by sequence length (same
+// acceptance rules as decode_lead).  Returns 1 when the character is alphabetic, 0 when it is in neither class or
+// malformed, and its length (2 or 3) negated when it is whitespace; only the lead bytes C2, E1, E2, E3 can begin
+// a whitespace character.  q[j + 1 .. j + 3] must be readable.
+template <class B>
+TRP_HD int classify_lead_at(const B& q, int j, const UniTables& ut) {
+    const u32 b0 = q[j], b1 = q[j + 1];
+    if ((b1 & 0xC0u) != 0x80u) return 0;
+    if (b0 < 0xE0u) {
+        const u32 cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+        if (cp == 0x85u || cp == 0xA0u) return -2;
+        return cp_is_alpha_high(cp, ut) ? 1 : 0;
+    }
+    const u32 b2 = q[j + 2];
+    if ((b2 & 0xC0u) != 0x80u) return 0;
+    if (b0 < 0xF0u) {
+        const u32 cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+        if (b0 <= 0xE3u && b0 != 0xE0u && cp_is_ws_high(cp)) return -3;
+        return cp_is_alpha_high(cp, ut) ? 1 : 0;
+    }
+    const u32 b3 = q[j + 3];
+    if ((b3 & 0xC0u) != 0x80u) return 0;
+    const u32 cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+    return cp_is_alpha_high(cp, ut) ? 1 : 0;
+}
+
+// Continuation bytes at the very start of a block whose character began in an earlier block: the ones that
+// belong to a whitespace character (found by looking back for the lead byte).  `high`: the bytes >= 0x80 of the
+// block, `cont6`: bit plane 6 of the block (clear on continuation bytes).
+template <class B>
+TRP_HD u64 head_ws_by_lookback(const B& blk, u64 high, u64 plane6) {
+    u64 ws = 0;
+    const u64 head = high & ~plane6 & 7ull;   // continuation bytes among the first three
+    for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
+        u32 cp;
+        for (int k = j + 1; k <= 3; k++) {   // the lead byte is before the block
+            u32 l = blk[j - k];
+            if (l >= 0xC0) {
+                int n = decode_lead(blk, j - k, &cp);
+                if (n > k && cp_is_ws_high(cp)) ws |= bit(j);
+                break;
+            }
+            if (l < 0x80) break;
+        }
+    }
+    return ws;
+}
+
+// The ASCII classes as boolean formulas over the bit planes; mb_ws / mb_alp: what the multi-byte characters add.
+TRP_HD Cls classes_from_planes(const u64 (&b)[8], u64 V, u64 mb_ws, u64 mb_alp) {
+    const u64 n7 = ~b[7] & V;
+    const u64 lowq = n7 & ~b[6] & ~b[5] & ~b[4];                 // 0x00-0x0F
+    const u64 ctl = lowq & b[3];                                 // 0x08-0x0F
+    Cls c;
+    c.nl = ctl & ~b[2] & b[1] & ~b[0];                           // 0x0A
+    c.cr = ctl & b[2] & ~b[1] & b[0];                            // 0x0D
+    const u64 wsc = ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1]); // 0x09-0x0D
+    const u64 sp = n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]);   // 0x20
+    c.ws = wsc | sp | mb_ws;
+    c.sp = sp;
+    c.dig = n7 & ~b[6] & b[5] & b[4] & ~(b[3] & (b[2] | b[1]));  // 0x30-0x39
+    const u64 nz5 = b[4] | b[3] | b[2] | b[1] | b[0];
+    const u64 gt26 = b[4] & b[3] & (b[2] | (b[1] & b[0]));
+    c.alp = (n7 & b[6] & nz5 & ~gt26) | mb_alp;                  // A-Z a-z
+    c.pipe = n7 & b[6] & b[5] & b[4] & b[3] & b[2] & ~b[1] & ~b[0];   // 0x7C
+    return c;
+}
+
+// The multi-byte characters of a block from its bit planes b: the bytes of its whitespace characters (*mb_ws)
+// and the lead bytes of its alphabetic characters (*mb_alp).
 template <class B, class X>
-TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut, X& nb) {
-    u32 w[16];
-TRP_UNROLL
-    for (int k = 0; k < 16; k++) w[k] = blk.word(k);
-    u64 b[8];
-    transpose_block(w, b);
-    const u64 V = below(nvalid);
+TRP_HD void mb_classify_planes(const B& blk, const u64 (&b)[8], u64 V, const UniTables& ut, X& nb, u64* out_ws,
+                               u64* out_alp) {
     // Bytes >= 0x80 first (few values are live here).  Only lead bytes (11xxxxxx) are decoded; a
     // whitespace character marks all its bytes, an alphabetic one its lead byte.  Continuation bytes at
     // the very start of the block belong to a character that began in the previous block: the previous
@@ -466,7 +538,8 @@ TRP_UNROLL
     const u64 high = b[7] & V;
     u64 lead = high & b[6];
     bool look_back = true;
-    if (nb.any(high != 0)) {
+    const bool any_high = nb.any(high != 0);
+    if (any_high) {
         u32 lo[8], hi[8];
 TRP_UNROLL
         for (int k = 0; k < 8; k++) { lo[k] = (u32)b[k]; hi[k] = (u32)(b[k] >> 32); }
@@ -497,62 +570,32 @@ TRP_UNROLL
             look_back = (from_prev & 4u) != 0;
         }
     }
-    while (lead) {
-        const int j = ctz(lead);
-        lead &= lead - 1;
-        // straight-line decode by sequence length (same acceptance rules as decode_lead); only the lead
-        // bytes C2, E1, E2, E3 can begin a whitespace character
-        const u32 b0 = blk[j], b1 = blk[j + 1];
-        if ((b1 & 0xC0u) != 0x80u) continue;
-        if (b0 < 0xE0u) {
-            const u32 cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
-            if (cp == 0x85u || cp == 0xA0u) mb_ws |= (3ull << j) & V;
-            else if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
-            continue;
-        }
-        const u32 b2 = blk[j + 2];
-        if ((b2 & 0xC0u) != 0x80u) continue;
-        if (b0 < 0xF0u) {
-            const u32 cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
-            if (b0 <= 0xE3u && b0 != 0xE0u && cp_is_ws_high(cp)) mb_ws |= (7ull << j) & V;
-            else if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
-            continue;
-        }
-        const u32 b3 = blk[j + 3];
-        if ((b3 & 0xC0u) != 0x80u) continue;
-        const u32 cp = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
-        if (cp_is_alpha_high(cp, ut)) mb_alp |= bit(j);
-    }
-    u64 head = look_back ? high & ~b[6] & 7ull : 0ull;   // continuation bytes among the first three
-    for (int j = 0; j < 3 && ((head >> j) & 1ull); j++) {
-        u32 cp;
-        for (int k = j + 1; k <= 3; k++) {   // the lead byte is before the block
-            u32 l = blk[j - k];
-            if (l >= 0xC0) {
-                int n = decode_lead(blk, j - k, &cp);
-                if (n > k && cp_is_ws_high(cp)) mb_ws |= bit(j);
-                break;
-            }
-            if (l < 0x80) break;
+    // what the rules have not settled: the group may take the characters on together (leftover), otherwise the
+    // block decodes its own, one after the other
+    if (!any_high || !nb.leftover(blk, lead, V, ut, &mb_ws, &mb_alp)) {
+        while (lead) {
+            const int j = ctz(lead);
+            lead &= lead - 1;
+            const int k = classify_lead_at(blk, j, ut);
+            if (k > 0) mb_alp |= bit(j);
+            else if (k < 0) mb_ws |= ((k == -2 ? 3ull : 7ull) << j) & V;
         }
     }
-    // ASCII classes: boolean formulas over the planes
-    const u64 n7 = ~b[7] & V;
-    const u64 lowq = n7 & ~b[6] & ~b[5] & ~b[4];                 // 0x00-0x0F
-    const u64 ctl = lowq & b[3];                                 // 0x08-0x0F
-    Cls c;
-    c.nl = ctl & ~b[2] & b[1] & ~b[0];                           // 0x0A
-    c.cr = ctl & b[2] & ~b[1] & b[0];                            // 0x0D
-    const u64 wsc = ctl & (b[2] | b[1] | b[0]) & ~(b[2] & b[1]); // 0x09-0x0D
-    const u64 sp = n7 & ~b[6] & b[5] & ~(b[4] | b[3] | b[2] | b[1] | b[0]);   // 0x20
-    c.ws = wsc | sp | mb_ws;
-    c.sp = sp;
-    c.dig = n7 & ~b[6] & b[5] & b[4] & ~(b[3] & (b[2] | b[1]));  // 0x30-0x39
-    const u64 nz5 = b[4] | b[3] | b[2] | b[1] | b[0];
-    const u64 gt26 = b[4] & b[3] & (b[2] | (b[1] & b[0]));
-    c.alp = (n7 & b[6] & nz5 & ~gt26) | mb_alp;                  // A-Z a-z
-    c.pipe = n7 & b[6] & b[5] & b[4] & b[3] & b[2] & ~b[1] & ~b[0];   // 0x7C
-    return c;
+    if (look_back) mb_ws |= head_ws_by_lookback(blk, high, b[6]);
+    *out_ws = mb_ws;
+    *out_alp = mb_alp;
+}
+template <class B, class X>
+TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut, X& nb) {
+    u32 w[16];
+TRP_UNROLL
+    for (int k = 0; k < 16; k++) w[k] = blk.word(k);
+    u64 b[8];
+    transpose_block(w, b);
+    const u64 V = below(nvalid);
+    u64 mb_ws, mb_alp;
+    mb_classify_planes(blk, b, V, ut, nb, &mb_ws, &mb_alp);
+    return classes_from_planes(b, V, mb_ws, mb_alp);
 }
 template <class B>
 TRP_HD Cls classify_block_fast(const B& blk, int nvalid, const UniTables& ut) {
@@ -731,32 +774,49 @@ TRP_HD J j_combine(const J& A, const J& B) {
     return C;
 }
 
+// Statistics of the bytes R of one line (R lies inside the valid bytes; digits, letters and pipes are never
+// terminators).  nws: the bytes of the block that are not whitespace (terminators are whitespace).  Without
+// branches or bit searches: with np / nt the pipes / the other non-whitespace bytes of R, the last one is a pipe
+// when np > nt as numbers (the highest bit decides), the first one when the same holds for the mirror images.
+TRP_HD LineSum line_part_sum(const Cls& c, u64 nws, u64 R) {
+    LineSum s;
+    s.d = (u32)popc(c.dig & R);
+    s.a = (u32)popc(c.alp & R);
+    s.p = (u32)popc(c.pipe & R);
+    const u64 nw = R & nws, np = nw & c.pipe, nt = nw ^ np;
+    const u32 first = nw ? (brev(np) > brev(nt) ? 1u : 2u) : 0u;
+    const u32 last = nw ? (np > nt ? 1u : 2u) : 0u;
+    s.f = first | (last << 2) | (nt ? 16u : 0u);
+    return s;
+}
+
 TRP_HD J lane_J(const Cls& c, const Derived& d) {
     J j;
-    u32 g = 0;
-    // two range sums on every path (lanes with and without a line start sit in the same wavefront)
     const bool has_ls = d.LS != 0;
-    const int first = has_ls ? ctz(d.LS) : 64, last = has_ls ? top(d.LS) : 0;
-    j.head = range_sum(c, d, below(first));                 // the whole block when it has no line start
-    j.tail = range_sum(c, d, has_ls ? ~below(last) : 0ull);
+    const u64 nws = d.V & ~c.ws;
+    // before the first line start (the whole block when it has none); from the last line start on
+    const u64 Rh = ((d.LS & (0ull - d.LS)) - 1ull) & d.V;
+    const u64 Rt = has_ls ? (~below(top(d.LS)) & d.V) : 0ull;
+    j.head = line_part_sum(c, nws, Rh);
+    j.tail = line_part_sum(c, nws, Rt);
+    // alphabetic characters since the last record start (or the start of the block) before each byte; the carry
+    // out of the last byte is "an alphabetic character at or after the last record start"
+    const u64 alp = c.alp & d.V;
+    const u64 K = d.RS >> 1, X = ~K, Y = alp & X;
+    const u64 sum = X + Y;
+    const u64 FA = sum ^ X ^ Y;
+    const bool at_after = sum < X;
+    const u64 first_rs_below = (d.RS & (0ull - d.RS)) - 1ull;      // bytes before the first record start (all without one)
+    u32 g = 0;
     if (has_ls) {
         g |= G_LS;
-        u64 rsb = d.RS & below(last + 1);
-        if (rsb) {
-            if (c.alp & below(last) & ~below(top(rsb))) g |= G_C0;
-        } else {
-            if (c.alp & below(last)) g |= G_C0;
-            g |= G_C1;
-        }
+        const u64 last_ls = d.LS & Rt;                               // the last line start alone
+        if (FA & last_ls) g |= G_C0;
+        if (!(d.RS & (last_ls | (last_ls - 1ull)))) g |= G_C1;       // no record start at or before it
     }
-    u64 alp = c.alp & d.V;
-    if (d.RS == 0) {
-        if (alp) g |= G_AH | G_AT;
-    } else {
-        g |= G_RS;
-        if (alp & below(ctz(d.RS))) g |= G_AH;
-        if (alp & ~below(top(d.RS))) g |= G_AT;
-    }
+    if (d.RS) g |= G_RS;
+    if (alp & first_rs_below) g |= G_AH;
+    if (at_after) g |= G_AT;
     j.g = g;
     return j;
 }

@@ -263,7 +263,11 @@ static int sim_run(const uint8_t* bytes, const uint64_t* offsets, uint64_t R, co
                     };
                     u64 Kw[G3_WORDS + 1] = {0, 0, 0, 0, 0}, KSw[G3_WORDS + 1] = {0, 0, 0, 0, 0};
                     const u32 s0 = (u32)(p & 63), e0 = (u32)(e - w0 * 64);
-                    if (e - p <= 64u * G3_SHORT) {
+                    if (e - p <= 64u) {   // one-word masks (the device's list of short lines)
+                        u64 K1[2], S1[2];
+                        g3_solve_shifted<1>(masks, s0, e0, rt, K1, S1);
+                        for (int i = 0; i <= 1; i++) { Kw[i] = K1[i]; KSw[i] = S1[i]; }
+                    } else if (e - p <= 64u * G3_SHORT) {
                         u64 K2[G3_SHORT + 1], S2[G3_SHORT + 1];
                         g3_solve_shifted<G3_SHORT>(masks, s0, e0, rt, K2, S2);
                         for (int i = 0; i <= G3_SHORT; i++) { Kw[i] = K2[i]; KSw[i] = S2[i]; }
