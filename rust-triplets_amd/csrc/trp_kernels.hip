@@ -148,6 +148,8 @@ __device__ inline void wave_lds_sync() {
 }
 
 __device__ inline u32 readlane_u32(u32 v, int lane) { return (u32)__builtin_amdgcn_readlane((int)v, lane); }
+// This lane's bit of a mask that is the same in every lane (one bit per lane, as a ballot returns it).
+__device__ inline u32 lane_bit(u64 uniform_mask) { return (u32)(uniform_mask >> (threadIdx.x & 63)) & 1u; }
 
 // ---- line carries of a tile from wave prefix sums and ballots ----------------------------------------
 // What a lane has to know about the blocks around it (LaneCarry) is a segmented sum over the lanes back
@@ -416,16 +418,15 @@ __device__ inline LaneCarry near_carry(const WaveLines& W, const NearLines& Q, u
     LaneCarry k;
     const int f = ctz(W.lsm), l = top(W.lsm);
     const bool pw_ar = (Pw.g & G_RS) ? (Pw.g & G_AT) != 0 : (Pw.g & G_AH) != 0;
-    // the record has an alphabetic char before this block
+    // The record has an alphabetic char before this block: a prefix OR over the lanes that starts afresh at every
+    // lane with a record start, for all lanes at once as the carries of one addition on the ballots (uniform
+    // values, scalar instructions).  A lane with a record start hands on "alpha at or after my last record start"
+    // and nothing of what came before; any other lane hands on what it got, or that it has an alpha itself.
     {
-        const u64 bn = below(L);
-        const u64 rb = W.rsm & bn;
-        if (rb) {
-            const int r = top(rb);
-            k.ar_in = ((W.gat >> r) & 1ull) || (W.gah & bn & ~below(r + 1)) != 0;
-        } else {
-            k.ar_in = pw_ar || (W.gah & bn) != 0;
-        }
+        const u64 kill = W.rsm & ~W.gat, gen = (W.rsm & W.gat) | (~W.rsm & W.gah);
+        const u64 X = ~kill, Y = gen;
+        const u64 sum = X + Y + (pw_ar ? 1ull : 0ull);
+        k.ar_in = lane_bit(sum ^ X ^ Y) != 0;   // the carry into this lane
     }
     // "the record has an alphabetic char before this line's start", as the lane that holds the line start sees it
     const u32 rab_own = ((own_g & G_C0) != 0 || ((own_g & G_C1) != 0 && k.ar_in)) ? 1u : 0u;
@@ -1334,11 +1335,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
     bool head_g3 = false;   // the line that runs into this block is a digit-heavy line (marked at its first byte)
     Plan pl = NORMALIZE ? plan_normalize(L.c, L.d, k.ar_in, L.prev_tok, L.sp)
                         : plan_block(L.c, L.d, k, cfg, rt, unpack_ls8(own_head), unpack_ls8(own_tail), &head_g3, false);
+    // (the plan is brought into its canonical form, plan_fold_prefixes, once the digit-heavy lines of the tile are
+    // in it: the markers and what is known so far are not touched by that step)
     u64 sp_nl = 0;
-    if (!NORMALIZE) {
-        sp_nl = (u64)park[0] | ((u64)park[1] << 32);
-        plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, L.d.V);
-    }
+    if (!NORMALIZE) sp_nl = (u64)park[0] | ((u64)park[1] << 32);
     // Digit-heavy lines (gate 3) are marked by plan_block at their first byte.  Lines that fit are solved
     // right here, one wavefront per line, on the per-block masks (the byte image is overwritten).
     if (stop_after == 4) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL; return; }
@@ -1434,12 +1434,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
             pl.C |= gm.G[tid];
             pl.TOK |= gm.G[tid];
             marks = left;
-            {   // the separators of the kept tokens
-                const u64 sn = sh.w.tokc[tid];
-                plan_fold_prefixes(pl, sn & L.d.LC, sn & ~L.d.LC, below(L.nvalid));
-            }
         }
+        sp_nl = sh.w.tokc[tid];
     }
+    if (!NORMALIZE) plan_fold_prefixes(pl, sp_nl & L.d.LC, sp_nl & ~L.d.LC, L.d.V);
     if (stop_after == 5) { if (pl.C == 0x123456789ull) g3list[0] = pl.TOK ^ pl.PSP ^ pl.PNL ^ marks; return; }
     {
         // separator planes: for blocks with a separator, with the marker of a line left for k_gate3_solve, or
@@ -2669,7 +2667,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
     // stop_after != 0 (profiling aid, see trp_ctx::emit_stop) ends every sub-tile after that phase
     if (stop_after == 1) return;
     // the neighbours' edge bits through the cross-lane network
-    const u32 up = (u32)__shfl_up((int)(TOKC >> 31), 1, 64), down = (u32)__shfl_down((int)(TOKC & 1u), 1, 64);
+    const u32 up = from_prev_lane(TOKC >> 31), down = from_next_lane(TOKC & 1u);   // (lanes 0 / 63 get 0 and use the edge words)
     const bool prev_tok = tid > 0 ? up != 0 : edge_prev;
     const bool next_tok = tid < 63 ? down != 0 : edge_next;
     const u32 TS = TOKC & (~((TOKC << 1) | (prev_tok ? 1u : 0u)) | RS);
@@ -2683,8 +2681,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
     const u32 tok0 = (u32)(tb64 >> 32);                                      // index of the first token that starts in it
     const u32 ex_a = inc_a - me_a;
     const u32 ex_nb = out0 + (ex_a & 0xFFFFu), ex_ntk = tok0 + (ex_a >> 16);
-    const u32 up_l = (u32)__shfl_up((int)inc_l, 1, 64);   // every lane takes part
-    const u32 ex_l = tid > 0 ? up_l : 0u;
+    const u32 ex_l = from_prev_lane(inc_l);   // (0 in lane 0)
     const int ex_lts = (int)ex_l - 1;   // sub-tile-relative position of the last token start before this lane, -1 none
     const u32 tot_a = readlane_u32(inc_a, 63);
     const u32 total_nb = out0 + (tot_a & 0xFFFFu);
