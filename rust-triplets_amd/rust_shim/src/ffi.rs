@@ -4,6 +4,10 @@ use std::os::raw::{c_char, c_int, c_void};
 
 pub const TRP_OK: c_int = 0;
 pub const TRP_MAX_BATCH_BYTES: u64 = 0xFFFF_0000;
+pub const TRP_OUT_TEXT: u32 = 1;
+pub const TRP_OUT_TOKENS: u32 = 2;
+pub const TRP_OUT_CHUNKS: u32 = 4;
+pub const TRP_OUT_CHUNK_TEXT: u32 = 8;
 pub const TRP_OUT_ALL: u32 = 7;
 
 #[repr(C)]
@@ -51,8 +55,17 @@ pub struct trp_result {
     pub n_chunks: u64,
 }
 
+/// Texts rendered on the GPU, in library-owned host memory (release with `trp_chunk_text_free`).
+#[repr(C)]
+pub struct trp_chunk_text {
+    pub text: *mut u8,
+    pub offsets: *mut u64,
+    pub n_bytes: u64,
+}
+
 extern "C" {
     pub fn trp_create(device: c_int, out: *mut *mut trp_ctx) -> c_int;
+    pub fn trp_device_count() -> c_int;
     pub fn trp_destroy(ctx: *mut trp_ctx);
     pub fn trp_last_error() -> *const c_char;
     pub fn trp_preprocess_batch(
@@ -72,9 +85,43 @@ extern "C" {
         cfg: *const trp_config,
         outputs: u32,
         out: *mut trp_result,
-        chunk_text: *mut c_void,
+        chunk_text: *mut trp_chunk_text,
     ) -> c_int;
     pub fn trp_result_free(r: *mut trp_result);
+    pub fn trp_chunk_text_free(t: *mut trp_chunk_text);
+    /// record_bm25_text (src/sampler/backends/bm25_backend.rs:503-532) over a packed host batch.
+    pub fn trp_bm25_texts(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        doc_offsets: *const u64,
+        n_docs: u64,
+        max_tokens: u32,
+        newline: *const c_char,
+        out: *mut trp_chunk_text,
+    ) -> c_int;
+    /// The BM25 query cap (bm25_backend.rs:219-225): every record cut to its first `max_tokens` tokens.
+    pub fn trp_head_tokens_text(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        max_tokens: u32,
+        out: *mut trp_chunk_text,
+    ) -> c_int;
+    /// Bodies of selected chunks cut to a token budget (decorate_chunk, src/sampler/mod.rs:1497-1504).
+    pub fn trp_chunk_bodies(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        cfg: *const trp_config,
+        chunk_index: *const u32,
+        budget: *const u32,
+        n: u64,
+        out: *mut trp_chunk_text,
+    ) -> c_int;
     pub fn trp_denoise(
         ctx: *mut trp_ctx,
         text: *const u8,

@@ -15,9 +15,9 @@
 //! environment has no Rust toolchain); the tested host sides are the C++ and Python ones.
 pub mod ffi;
 
-use std::collections::HashMap;
+use std::collections::{HashMap, VecDeque};
 use std::ffi::CStr;
-use std::sync::{Mutex, RwLock};
+use std::sync::{Arc, Mutex, RwLock};
 
 use triplets::config::{ChunkingStrategy, DenoiserConfig};
 use triplets::data::{ChunkView, DataRecord, RecordChunk, RecordSection};
@@ -75,6 +75,17 @@ impl Drop for Batch {
     }
 }
 
+/// Chunk text rendered on the GPU (library-owned host memory).
+struct ChunkText {
+    raw: ffi::trp_chunk_text,
+}
+unsafe impl Send for ChunkText {}
+impl Drop for ChunkText {
+    fn drop(&mut self) {
+        unsafe { ffi::trp_chunk_text_free(&mut self.raw) };
+    }
+}
+
 impl Batch {
     /// `outputs`: TRP_OUT_* selection (0 = per-record arrays only, enough for token counts).
     fn run(
@@ -92,15 +103,7 @@ impl Batch {
             offsets.push(bytes.len() as u64);
         }
         let overlaps: Vec<u32> = st.overlap_tokens.iter().map(|&o| o.min(u32::MAX as usize) as u32).collect();
-        let cfg = ffi::trp_config {
-            denoise_enabled: denoiser.map_or(0, |d| d.enabled as u8),
-            strip_markdown: denoiser.map_or(1, |d| d.strip_markdown as u8),
-            max_digit_ratio: denoiser.map_or(0.35, |d| d.max_digit_ratio),
-            max_window_tokens: st.max_window_tokens.min(u32::MAX as usize) as u32,
-            overlaps: overlaps.as_ptr(),
-            n_overlaps: overlaps.len() as u32,
-            summary_fallback_tokens: st.summary_fallback_tokens.min(u32::MAX as usize) as u32,
-        };
+        let cfg = Self::config(denoiser, st, &overlaps);
         let mut raw: ffi::trp_result = unsafe { std::mem::zeroed() };
         let guard = ctx.raw.lock().unwrap();
         let rc = unsafe {
@@ -112,7 +115,7 @@ impl Batch {
                 &cfg,
                 outputs,
                 &mut raw,
-                std::ptr::null_mut(),
+                std::ptr::null_mut::<ffi::trp_chunk_text>(),
             )
         };
         drop(guard);
@@ -122,6 +125,75 @@ impl Batch {
             return Err(e);
         }
         Ok(Batch { raw })
+    }
+
+    fn config(denoiser: Option<&DenoiserConfig>, st: &ChunkingStrategy, overlaps: &[u32]) -> ffi::trp_config {
+        ffi::trp_config {
+            denoise_enabled: denoiser.map_or(0, |d| d.enabled as u8),
+            strip_markdown: denoiser.map_or(1, |d| d.strip_markdown as u8),
+            max_digit_ratio: denoiser.map_or(0.35, |d| d.max_digit_ratio),
+            max_window_tokens: st.max_window_tokens.min(u32::MAX as usize) as u32,
+            overlaps: overlaps.as_ptr(),
+            n_overlaps: overlaps.len() as u32,
+            summary_fallback_tokens: st.summary_fallback_tokens.min(u32::MAX as usize) as u32,
+        }
+    }
+
+    /// Chunk descriptors + the text of every chunk rendered on the GPU (what a `materialize` table needs): the
+    /// preprocessed text and the token table stay on the device.
+    fn run_with_chunk_text(
+        ctx: &Context,
+        texts: &[&str],
+        denoiser: Option<&DenoiserConfig>,
+        st: &ChunkingStrategy,
+    ) -> Result<(Batch, ChunkText), String> {
+        let (bytes, offsets) = pack(texts);
+        let overlaps: Vec<u32> = st.overlap_tokens.iter().map(|&o| o.min(u32::MAX as usize) as u32).collect();
+        let cfg = Self::config(denoiser, st, &overlaps);
+        let mut raw: ffi::trp_result = unsafe { std::mem::zeroed() };
+        let mut ct: ffi::trp_chunk_text = unsafe { std::mem::zeroed() };
+        let guard = ctx.raw.lock().unwrap_or_else(|p| p.into_inner());
+        let rc = unsafe {
+            ffi::trp_preprocess_batch_select(
+                *guard,
+                bytes.as_ptr(),
+                offsets.as_ptr(),
+                texts.len() as u64,
+                &cfg,
+                ffi::TRP_OUT_CHUNKS | ffi::TRP_OUT_CHUNK_TEXT,
+                &mut raw,
+                &mut ct,
+            )
+        };
+        drop(guard);
+        if rc != ffi::TRP_OK {
+            let e = last_error();
+            log_error("trp_preprocess_batch_select");
+            return Err(e);
+        }
+        Ok((Batch { raw }, ChunkText { raw: ct }))
+    }
+
+    /// Chunk prototypes of section `r` from the descriptors and the GPU-rendered chunk text.
+    fn chunks_with_text(&self, r: usize, ct: &ChunkText, summary_weight: f32) -> Vec<Proto> {
+        let res = &self.raw;
+        let n = res.n_records as usize;
+        let ch_off = Self::slice(res.chunk_offsets as *const u64, n + 1);
+        let chunks = Self::slice(res.chunks as *const ffi::trp_chunk, res.n_chunks as usize);
+        let t_off = Self::slice(ct.raw.offsets as *const u64, res.n_chunks as usize + 1);
+        let text = Self::slice(ct.raw.text as *const u8, ct.raw.n_bytes as usize);
+        (ch_off[r] as usize..ch_off[r + 1] as usize)
+            .map(|i| {
+                let c = &chunks[i];
+                let view = if c.kind == 0 {
+                    ChunkView::Window { index: c.index as usize, overlap: c.overlap as usize, span: c.span as usize }
+                } else {
+                    ChunkView::SummaryFallback { strategy: "head".into(), weight: summary_weight }
+                };
+                let s = String::from_utf8_lossy(&text[t_off[i] as usize..t_off[i + 1] as usize]).into_owned();
+                (view, s, (c.tok_end - c.tok_begin) as usize)
+            })
+            .collect()
     }
 
     fn token_count(&self, r: usize) -> usize {
@@ -206,15 +278,58 @@ fn strategy_fingerprint(st: &ChunkingStrategy, den: Option<&DenoiserConfig>) -> 
     h
 }
 
+/// 64-bit hash of a section text (eight bytes per step, final avalanche): an entry is only served for the
+/// text it was made from.
+fn text_hash(t: &str) -> u64 {
+    let b = t.as_bytes();
+    let mut h: u64 = 0x9E37_79B9_7F4A_7C15 ^ b.len() as u64;
+    let mut chunks = b.chunks_exact(8);
+    for c in &mut chunks {
+        let v = u64::from_le_bytes(c.try_into().unwrap());
+        h = (h ^ v).wrapping_mul(0x0000_0100_0000_01B3);
+        h ^= h >> 29;
+    }
+    let mut tail = [0u8; 8];
+    let rest = chunks.remainder();
+    tail[..rest.len()].copy_from_slice(rest);
+    h = (h ^ u64::from_le_bytes(tail)).wrapping_mul(0x0000_0100_0000_01B3);
+    h ^= h >> 32;
+    h = h.wrapping_mul(0xD6E8_FEB8_6659_FD93);
+    h ^ (h >> 32)
+}
+
+struct Entry {
+    protos: Arc<Vec<Proto>>,
+    text_hash: u64,
+    text_len: usize,
+    cost: usize,
+    serial: u64,
+}
+
+#[derive(Default)]
+struct Table {
+    map: HashMap<Key, Entry>,
+    raw_tokens: HashMap<(String, usize), usize>,
+    order: VecDeque<(u64, Key)>, // insertion order: the rolling part (src/ingestion.rs:18)
+    bytes: usize,
+    serial: u64,
+}
+
+/// A section that missed the table, shared between the thread that waits for it and the thread that computes it.
 struct Miss {
     key: Key,
-    text: *const str, // the caller's section text; the caller is blocked until `done`
-    strategy: *const ChunkingStrategy,
-    done: bool,
+    text: String,
+    strategy: ChunkingStrategy,
+    slot: Mutex<Option<Result<Arc<Vec<Proto>>, String>>>,
 }
 
 /// `ChunkingAlgorithm` served from GPU batches.  Build it with the denoiser settings it should apply
 /// (do NOT also register a `DenoiserPreprocessor` on the strategy: the GPU path already denoises).
+///
+/// The reference's `materialize` is a function of the section text it is handed
+/// (src/chunking/sliding_window.rs:18): an entry remembers the length and a hash of the text it was made from,
+/// and a lookup with another text under the same id is a miss that replaces it.  The table keeps at most
+/// `budget_bytes` of chunk text and drops the entries inserted first beyond that; `invalidate` drops a record.
 ///
 /// A strategy that carries registered preprocessors (`strategy.preprocessors()` non-empty) cannot be
 /// served: the GPU path implements the denoiser only, and running arbitrary host preprocessors would
@@ -223,22 +338,26 @@ struct Miss {
 pub struct GpuSlidingWindowChunker {
     ctx: Context,
     denoiser: Option<DenoiserConfig>,
-    table: RwLock<HashMap<Key, Vec<Proto>>>,
-    raw_tokens: RwLock<HashMap<(String, usize), usize>>,
-    queue: Mutex<Vec<*mut Miss>>,
+    table: RwLock<Table>,
+    budget_bytes: usize,
+    queue: Mutex<Vec<Arc<Miss>>>,
     gpu: Mutex<()>,
     error: Mutex<Option<String>>,
 }
-unsafe impl Send for GpuSlidingWindowChunker {}
-unsafe impl Sync for GpuSlidingWindowChunker {}
+
+pub const DEFAULT_BUDGET_BYTES: usize = 1 << 30;
 
 impl GpuSlidingWindowChunker {
     pub fn new(device: i32, denoiser: Option<DenoiserConfig>) -> Result<Self, String> {
+        Self::with_budget(device, denoiser, DEFAULT_BUDGET_BYTES)
+    }
+
+    pub fn with_budget(device: i32, denoiser: Option<DenoiserConfig>, budget_bytes: usize) -> Result<Self, String> {
         Ok(Self {
             ctx: Context::new(device)?,
             denoiser,
-            table: RwLock::new(HashMap::new()),
-            raw_tokens: RwLock::new(HashMap::new()),
+            table: RwLock::new(Table::default()),
+            budget_bytes,
             queue: Mutex::new(Vec::new()),
             gpu: Mutex::new(()),
             error: Mutex::new(None),
@@ -247,11 +366,11 @@ impl GpuSlidingWindowChunker {
 
     /// The first GPU failure since the last call, if any (the traits cannot return it).
     pub fn take_error(&self) -> Option<String> {
-        self.error.lock().unwrap().take()
+        self.error.lock().unwrap_or_else(|p| p.into_inner()).take()
     }
 
     fn fail(&self, e: String) -> String {
-        let mut slot = self.error.lock().unwrap();
+        let mut slot = self.error.lock().unwrap_or_else(|p| p.into_inner());
         if slot.is_none() {
             *slot = Some(e.clone());
         }
@@ -275,7 +394,7 @@ impl GpuSlidingWindowChunker {
                 texts.push(s.text.as_str());
             }
         }
-        let _gpu = self.gpu.lock().unwrap();
+        let _gpu = self.gpu.lock().unwrap_or_else(|p| p.into_inner());
         let mut at = 0;
         while at < texts.len() {
             // as many sections as fit one batch (a single section above the limit fails in the library)
@@ -290,9 +409,16 @@ impl GpuSlidingWindowChunker {
         Ok(())
     }
 
-    /// `gpu` held.  One batch for the chunks and, with a denoiser, one pass-through batch for the raw counts.
-    fn compute(&self, strategy: &ChunkingStrategy, keys: &[(String, usize)], texts: &[&str]) -> Result<(), String> {
-        let batch = Batch::run(&self.ctx, texts, self.denoiser.as_ref(), strategy, ffi::TRP_OUT_ALL)?;
+    /// `gpu` held.  One batch for the chunks - descriptors and chunk text rendered on the GPU, 1.03 bytes per
+    /// input byte over the link instead of the 2.44 of all arrays - and, with a denoiser, one pass-through batch
+    /// for the raw token counts.  Returns the prototypes it made, in the order of `keys`.
+    fn compute(
+        &self,
+        strategy: &ChunkingStrategy,
+        keys: &[(String, usize)],
+        texts: &[&str],
+    ) -> Result<Vec<Arc<Vec<Proto>>>, String> {
+        let (batch, chunk_text) = Batch::run_with_chunk_text(&self.ctx, texts, self.denoiser.as_ref(), strategy)?;
         let denoising = self.denoiser.as_ref().map_or(false, |d| d.enabled);
         let raw: Vec<usize> = if denoising {
             let plain = Batch::run(&self.ctx, texts, None, strategy, 0)?;
@@ -301,41 +427,89 @@ impl GpuSlidingWindowChunker {
             (0..texts.len()).map(|r| batch.token_count(r)).collect()
         };
         let fp = strategy_fingerprint(strategy, self.denoiser.as_ref());
-        let protos: Vec<Vec<Proto>> =
-            (0..texts.len()).map(|r| batch.chunks_of(r, strategy.summary_fallback_weight)).collect();
-        let mut table = self.table.write().unwrap();
-        let mut counts = self.raw_tokens.write().unwrap();
-        for ((key, p), n) in keys.iter().zip(protos).zip(raw) {
-            table.insert((fp, key.0.clone(), key.1), p);
-            counts.insert(key.clone(), n);
+        let protos: Vec<Arc<Vec<Proto>>> = (0..texts.len())
+            .map(|r| Arc::new(batch.chunks_with_text(r, &chunk_text, strategy.summary_fallback_weight)))
+            .collect();
+        let mut t = self.table.write().unwrap_or_else(|p| p.into_inner());
+        for (((key, p), n), text) in keys.iter().zip(protos.iter()).zip(raw).zip(texts) {
+            let k: Key = (fp, key.0.clone(), key.1);
+            if let Some(old) = t.map.remove(&k) {
+                t.bytes -= old.cost;
+            }
+            let cost = std::mem::size_of::<Entry>()
+                + key.0.len()
+                + p.iter().map(|c| std::mem::size_of::<Proto>() + c.1.len()).sum::<usize>();
+            t.serial += 1;
+            let serial = t.serial;
+            t.bytes += cost;
+            t.order.push_back((serial, k.clone()));
+            t.map.insert(k, Entry { protos: p.clone(), text_hash: text_hash(text), text_len: text.len(), cost, serial });
+            t.raw_tokens.insert(key.clone(), n);
         }
-        Ok(())
+        // the rolling part: the oldest entries go while the table is over its budget (the newest one stays)
+        while t.bytes > self.budget_bytes && t.order.len() > 1 {
+            let (serial, k) = t.order.pop_front().unwrap();
+            let stale = t.map.get(&k).map_or(true, |e| e.serial != serial);
+            if stale {
+                continue; // replaced or invalidated meanwhile
+            }
+            let e = t.map.remove(&k).unwrap();
+            t.bytes -= e.cost;
+            t.raw_tokens.remove(&(k.1, k.2));
+        }
+        Ok(protos)
     }
 
-    /// Token count of the raw text of a prefilled section.
+    /// Token count of the raw text of a section that is in the table.
     pub fn token_count(&self, record_id: &str, section_idx: usize) -> Option<usize> {
-        self.raw_tokens.read().unwrap().get(&(record_id.to_string(), section_idx)).copied()
+        let t = self.table.read().unwrap_or_else(|p| p.into_inner());
+        t.raw_tokens.get(&(record_id.to_string(), section_idx)).copied()
+    }
+
+    /// Bytes of chunk text (and bookkeeping) the table holds; never more than the budget after an insertion.
+    pub fn bytes(&self) -> usize {
+        self.table.read().unwrap_or_else(|p| p.into_inner()).bytes
+    }
+
+    /// Drops every entry of one record (all sections, all strategies).
+    pub fn invalidate(&self, record_id: &str) -> usize {
+        let mut t = self.table.write().unwrap_or_else(|p| p.into_inner());
+        let gone: Vec<Key> = t.map.keys().filter(|k| k.1 == record_id).cloned().collect();
+        for k in &gone {
+            if let Some(e) = t.map.remove(k) {
+                t.bytes -= e.cost;
+            }
+        }
+        t.raw_tokens.retain(|k, _| k.0 != record_id);
+        gone.len()
     }
 
     pub fn clear(&self) {
-        self.table.write().unwrap().clear();
-        self.raw_tokens.write().unwrap().clear();
+        let mut t = self.table.write().unwrap_or_else(|p| p.into_inner());
+        *t = Table::default();
     }
 
-    /// `gpu` held: everything queued right now, one batch per strategy fingerprint.
+    /// `gpu` held: everything queued right now, one batch per strategy fingerprint.  Every queued miss gets its
+    /// answer (or the error) through its own slot, whether or not the entry is still in the table afterwards.
     fn drain(&self) {
-        let mut work: Vec<*mut Miss> = std::mem::take(&mut *self.queue.lock().unwrap());
-        while let Some(&first) = work.first() {
-            let fp = unsafe { (*first).key.0 };
-            let (same, rest): (Vec<_>, Vec<_>) = work.into_iter().partition(|&m| unsafe { (*m).key.0 == fp });
-            let keys: Vec<(String, usize)> = same.iter().map(|&m| unsafe { ((*m).key.1.clone(), (*m).key.2) }).collect();
-            let texts: Vec<&str> = same.iter().map(|&m| unsafe { &*(*m).text }).collect();
-            let strategy = unsafe { &*(*same[0]).strategy };
-            if let Err(e) = self.compute(strategy, &keys, &texts) {
-                self.fail(e);
-            }
-            for &m in &same {
-                unsafe { (*m).done = true };
+        let mut work: Vec<Arc<Miss>> = std::mem::take(&mut *self.queue.lock().unwrap_or_else(|p| p.into_inner()));
+        while let Some(first) = work.first() {
+            let fp = first.key.0;
+            let (same, rest): (Vec<_>, Vec<_>) = work.into_iter().partition(|m| m.key.0 == fp);
+            let keys: Vec<(String, usize)> = same.iter().map(|m| (m.key.1.clone(), m.key.2)).collect();
+            let texts: Vec<&str> = same.iter().map(|m| m.text.as_str()).collect();
+            match self.compute(&same[0].strategy, &keys, &texts) {
+                Ok(protos) => {
+                    for (m, p) in same.iter().zip(protos) {
+                        *m.slot.lock().unwrap_or_else(|e| e.into_inner()) = Some(Ok(p));
+                    }
+                }
+                Err(e) => {
+                    self.fail(e.clone());
+                    for m in &same {
+                        *m.slot.lock().unwrap_or_else(|p| p.into_inner()) = Some(Err(e.clone()));
+                    }
+                }
             }
             work = rest;
         }
@@ -356,21 +530,42 @@ impl ChunkingAlgorithm for GpuSlidingWindowChunker {
             return Vec::new();
         }
         let key: Key = (strategy_fingerprint(strategy, self.denoiser.as_ref()), record.id.to_string(), section_idx);
-        let mut protos = self.table.read().unwrap().get(&key).cloned();
-        if protos.is_none() {
-            // miss: queue it; the first thread to get the GPU computes everything queued
-            let mut me = Miss { key: key.clone(), text: section.text.as_str(), strategy, done: false };
-            self.queue.lock().unwrap().push(&mut me);
-            {
-                let _gpu = self.gpu.lock().unwrap();
-                if !me.done {
-                    self.drain();
+        let th = text_hash(&section.text);
+        let hit = {
+            let t = self.table.read().unwrap_or_else(|p| p.into_inner());
+            t.map
+                .get(&key)
+                .filter(|e| e.text_len == section.text.len() && e.text_hash == th)
+                .map(|e| e.protos.clone())
+        };
+        let protos = match hit {
+            Some(p) => Some(p),
+            None => {
+                // miss, or the text under this id has changed: queue it (the queue owns its copy of the text and
+                // of the strategy, so a panic elsewhere leaves nothing dangling); the first thread to get the GPU
+                // computes everything queued
+                let me = Arc::new(Miss {
+                    key: key.clone(),
+                    text: section.text.clone(),
+                    strategy: strategy.clone(),
+                    slot: Mutex::new(None),
+                });
+                self.queue.lock().unwrap_or_else(|p| p.into_inner()).push(me.clone());
+                {
+                    let _gpu = self.gpu.lock().unwrap_or_else(|p| p.into_inner());
+                    if me.slot.lock().unwrap_or_else(|p| p.into_inner()).is_none() {
+                        self.drain();
+                    }
+                }
+                // a GPU failure leaves no answer: the error is kept (take_error) and logged
+                match me.slot.lock().unwrap_or_else(|p| p.into_inner()).take() {
+                    Some(Ok(p)) => Some(p),
+                    _ => None,
                 }
             }
-            protos = self.table.read().unwrap().get(&key).cloned();
-        }
-        // a GPU failure leaves the section out of the table: the error is kept (take_error) and logged
+        };
         protos
+            .map(|p| p.as_ref().clone())
             .unwrap_or_default()
             .into_iter()
             .map(|(view, text, tokens_estimate)| RecordChunk {
@@ -384,6 +579,188 @@ impl ChunkingAlgorithm for GpuSlidingWindowChunker {
             })
             .collect()
     }
+}
+
+// ---- the steps right after the path -----------------------------------------------------------------------
+
+fn pack(texts: &[&str]) -> (Vec<u8>, Vec<u64>) {
+    let mut bytes = Vec::with_capacity(texts.iter().map(|t| t.len()).sum());
+    let mut offsets = Vec::with_capacity(texts.len() + 1);
+    offsets.push(0u64);
+    for t in texts {
+        bytes.extend_from_slice(t.as_bytes());
+        offsets.push(bytes.len() as u64);
+    }
+    (bytes, offsets)
+}
+
+fn take_texts(ct: &mut ffi::trp_chunk_text, n: usize) -> Vec<String> {
+    let offs = Batch::slice(ct.offsets as *const u64, n + 1);
+    let text = Batch::slice(ct.text as *const u8, ct.n_bytes as usize);
+    let out = (0..n)
+        .map(|i| String::from_utf8_lossy(&text[offs[i] as usize..offs[i + 1] as usize]).into_owned())
+        .collect();
+    unsafe { ffi::trp_chunk_text_free(ct) };
+    out
+}
+
+/// `record_bm25_text` (src/sampler/backends/bm25_backend.rs:503-532) for many records in one GPU batch.
+/// `records`: (record id, [(heading, section text)]) - what the reference reads from a `DataRecord`.
+pub fn record_bm25_texts(
+    ctx: &Context,
+    records: &[(&str, Vec<(Option<&str>, &str)>)],
+    max_tokens: usize,
+    newline: &str,
+) -> Result<Vec<String>, String> {
+    let mut parts: Vec<&str> = Vec::new();
+    let mut doc: Vec<u64> = vec![0];
+    for (_, sections) in records {
+        for (heading, text) in sections {
+            if let Some(h) = heading {
+                parts.push(h);
+            }
+            parts.push(text);
+        }
+        doc.push(parts.len() as u64);
+    }
+    let (bytes, offsets) = pack(&parts);
+    let nl = std::ffi::CString::new(newline).map_err(|e| e.to_string())?;
+    let mut ct: ffi::trp_chunk_text = unsafe { std::mem::zeroed() };
+    let guard = ctx.raw.lock().unwrap_or_else(|p| p.into_inner());
+    let rc = unsafe {
+        ffi::trp_bm25_texts(
+            *guard,
+            bytes.as_ptr(),
+            offsets.as_ptr(),
+            parts.len() as u64,
+            doc.as_ptr(),
+            records.len() as u64,
+            max_tokens.min(u32::MAX as usize) as u32,
+            nl.as_ptr(),
+            &mut ct,
+        )
+    };
+    drop(guard);
+    if rc != ffi::TRP_OK {
+        return Err(last_error());
+    }
+    let mut out = take_texts(&mut ct, records.len());
+    for (t, (id, _)) in out.iter_mut().zip(records) {
+        if t.is_empty() {
+            *t = (*id).to_string(); // bm25_backend.rs:517-519
+        }
+    }
+    Ok(out)
+}
+
+/// The BM25 query cap (bm25_backend.rs:219-225): every text cut to its first `limit` tokens joined by one space,
+/// or left as it is when it has no more than that.
+pub fn cap_tokens(ctx: &Context, texts: &[&str], limit: usize) -> Result<Vec<String>, String> {
+    let (bytes, offsets) = pack(texts);
+    let mut ct: ffi::trp_chunk_text = unsafe { std::mem::zeroed() };
+    let guard = ctx.raw.lock().unwrap_or_else(|p| p.into_inner());
+    let rc = unsafe {
+        ffi::trp_head_tokens_text(
+            *guard,
+            bytes.as_ptr(),
+            offsets.as_ptr(),
+            texts.len() as u64,
+            limit.min(u32::MAX as usize) as u32,
+            &mut ct,
+        )
+    };
+    drop(guard);
+    if rc != ffi::TRP_OK {
+        return Err(last_error());
+    }
+    Ok(take_texts(&mut ct, texts.len()))
+}
+
+/// The body half of `decorate_chunk` (src/sampler/mod.rs:1497-1504) for many chunks in one GPU batch: the
+/// sections are preprocessed and chunked with `strategy` (and the denoiser, if any), chunk `chunk_index[i]` of
+/// the batch is cut to `budget[i]` tokens (`max_window_tokens - prefix_tokens`), verbatim when the budget covers
+/// it.  The prefix comes from the sampler's RNG (`KvpPrefixSampler::sample`) and is put in front by the caller.
+pub fn chunk_bodies(
+    ctx: &Context,
+    sections: &[&str],
+    denoiser: Option<&DenoiserConfig>,
+    strategy: &ChunkingStrategy,
+    chunk_index: &[u32],
+    budget: &[u32],
+) -> Result<Vec<String>, String> {
+    if chunk_index.len() != budget.len() {
+        return Err("chunk_index and budget differ in length".into());
+    }
+    let (bytes, offsets) = pack(sections);
+    let overlaps: Vec<u32> = strategy.overlap_tokens.iter().map(|&o| o.min(u32::MAX as usize) as u32).collect();
+    let cfg = Batch::config(denoiser, strategy, &overlaps);
+    let mut ct: ffi::trp_chunk_text = unsafe { std::mem::zeroed() };
+    let guard = ctx.raw.lock().unwrap_or_else(|p| p.into_inner());
+    let rc = unsafe {
+        ffi::trp_chunk_bodies(
+            *guard,
+            bytes.as_ptr(),
+            offsets.as_ptr(),
+            sections.len() as u64,
+            &cfg,
+            chunk_index.as_ptr(),
+            budget.as_ptr(),
+            chunk_index.len() as u64,
+            &mut ct,
+        )
+    };
+    drop(guard);
+    if rc != ffi::TRP_OK {
+        return Err(last_error());
+    }
+    Ok(take_texts(&mut ct, chunk_index.len()))
+}
+
+/// One batch of sections over several GPUs of this process: one context and one thread per entry of `devices`,
+/// byte-balanced contiguous ranges of sections, nothing exchanged between the GPUs.  Returns, per shard, the
+/// first section it holds and its chunk prototypes per section.
+pub fn preprocess_sharded(
+    devices: &[i32],
+    texts: &[&str],
+    denoiser: Option<&DenoiserConfig>,
+    strategy: &ChunkingStrategy,
+) -> Result<Vec<(usize, Vec<Vec<Proto>>)>, String> {
+    if devices.is_empty() {
+        return Err("preprocess_sharded needs at least one device".into());
+    }
+    let total: u64 = texts.iter().map(|t| t.len() as u64).sum();
+    let g = devices.len();
+    let mut cuts = vec![0usize; g + 1];
+    cuts[g] = texts.len();
+    let (mut at, mut seen) = (0usize, 0u64);
+    for k in 1..g {
+        let target = total * k as u64 / g as u64;
+        while at < texts.len() && seen < target {
+            seen += texts[at].len() as u64;
+            at += 1;
+        }
+        cuts[k] = at;
+    }
+    let ctxs: Vec<Context> = devices.iter().map(|&d| Context::new(d)).collect::<Result<_, _>>()?;
+    std::thread::scope(|scope| {
+        let handles: Vec<_> = (0..g)
+            .map(|k| {
+                let (ctx, part) = (&ctxs[k], &texts[cuts[k]..cuts[k + 1]]);
+                scope.spawn(move || -> Result<Vec<Vec<Proto>>, String> {
+                    let (batch, chunk_text) = Batch::run_with_chunk_text(ctx, part, denoiser, strategy)?;
+                    Ok((0..part.len())
+                        .map(|r| batch.chunks_with_text(r, &chunk_text, strategy.summary_fallback_weight))
+                        .collect())
+                })
+            })
+            .collect();
+        let mut out = Vec::with_capacity(g);
+        for (k, h) in handles.into_iter().enumerate() {
+            let protos = h.join().map_err(|_| "a shard thread panicked".to_string())??;
+            out.push((cuts[k], protos));
+        }
+        Ok(out)
+    })
 }
 
 /// `TextPreprocessor` that runs the denoiser on the GPU (a batch of one per call; prefer the chunker

@@ -46,7 +46,8 @@ def main():
         if rng.random() < 0.2:
             recs.insert(rng.randrange(len(recs) + 1), b"")
         enabled = rng.random() < 0.8
-        ratio = rng.choice([0.0, 0.1, 0.35, 0.35, 0.5, 0.9, 1.0])
+        ratio = rng.choice([0.0, 0.1, 0.35, 0.35, 0.5, 0.9, 1.0, 1.0 / 3.0, 0.34999999, 1e-9, -0.5, 1.5, float("nan"),
+                            float("inf"), 0.25, 0.75])
         md = rng.random() < 0.8
         mwt = rng.choice([1, 2, 7, 64, 1024])
         ov = tuple(rng.choice([0, 1, 3, 64, 2000]) for _ in range(rng.choice([0, 1, 1, 2, 3])))
