@@ -2400,6 +2400,9 @@ struct GenChunkCounts {
 };
 
 constexpr u64 SCAN_SUM_MAX = 8192;
+// Inputs of at most SCAN_SMALL_MAX values (batches of a few megabytes, a few thousand records) are scanned by one
+// workgroup in one launch: at that size a batch is bound by the number of dependent launches, not by bytes.
+constexpr u64 SCAN_SMALL_MAX = 4096;
 template <class Gen>
 __global__ __launch_bounds__(NT) void k_scan_reduce_gen(Gen gen, u64 n, u64* __restrict__ partial) {
     __shared__ u64 red[NT / 64];
@@ -2418,6 +2421,24 @@ __global__ __launch_bounds__(NT) void k_scan_reduce_gen(Gen gen, u64 n, u64* __r
         u64 tot = 0;
         for (int w = 0; w < NT / 64; w++) tot += red[w];
         partial[blockIdx.x] = tot;
+    }
+}
+template <class Gen>
+__global__ __launch_bounds__(NT) void k_scan_small_gen(Gen gen, u64 n, u64* __restrict__ out) {
+    __shared__ u64 smem[NT / 64];
+    const typename Gen::State st = gen.begin();
+    u64 carry = 0;
+    for (u64 base = 0; base < n; base += NT) {   // uniform
+        const u64 i = base + threadIdx.x;
+        const u64 v = i < n ? gen.at(st, i) : 0;
+        u64 tot;
+        const u64 ex = block_excl_sum_u64(v, smem, &tot);   // barriers inside
+        if (i < n) out[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        out[n] = carry;
+        gen.once();
     }
 }
 // k_scan_final with the workgroup's base summed from the (unscanned) partial sums of the workgroups before it
@@ -3305,6 +3326,11 @@ int scan_u64_with(hipStream_t st, u64* partial, const u64* in, u64 n, u64* out) 
 template <class Gen>
 int scan_gen(hipStream_t st, u64* partial, const Gen& gen, const u64* values, u64 n, u64* out) {
     const u64 nb = scan_partials(n);
+    if (n <= SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_scan_small_gen<Gen>, dim3(1), dim3(NT), 0, st, gen, n, out);
+        HIPCHK(hipGetLastError());
+        return TRP_OK;
+    }
     hipLaunchKernelGGL(k_scan_reduce_gen<Gen>, dim3((unsigned)nb), dim3(NT), 0, st, gen, n, partial);
     if (nb <= SCAN_SUM_MAX) {
         hipLaunchKernelGGL(k_scan_final_sum, dim3((unsigned)nb), dim3(NT), 0, st, values, n, partial, out);
@@ -3537,7 +3563,8 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                      B.seedJ, B.seedS, dc, c->ratio_arg, plan, B.g3list, B.g3_cap, totals + 6, tbytes,
                                      ttoks, tflags, c->plan_stop()); }
             { Prof pr(c, "k_gate3");
-              hipLaunchKernelGGL(k_gate3_solve, dim3(4096), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
+              // (any grid is right: the workgroups stride over the list; a small batch spares the dispatch of idle ones)
+              hipLaunchKernelGGL(k_gate3_solve, dim3((unsigned)std::min<u64>(4096, std::max<u64>(64, 8 * nT))), dim3(64), 0, st, d_bytes, d_offsets, rec_lo, R, N, nB, dc, plan,
                                  B.g3list, totals + 6, B.g3_cap, tbytes, ttoks, totals, B.denoised); }
         } else {
             Prof pr(c, "k_count_tokens");
@@ -3565,7 +3592,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
       gen.den_off = den_off; gen.tok_off = tok_off; gen.totals = totals; gen.counts = B.counts; gen.dropped = B.dropped;
       if ((rc = scan_gen(st, B.partial, gen, B.counts, R, chunk_off))) return rc; }
     { Prof pr(c, "k_chunk_emit");
-      hipLaunchKernelGGL(k_chunk_emit, dim3(1024), dim3(256), 0, st, chunk_off, tok_off, R, dc, B.chunk_cap,
+      hipLaunchKernelGGL(k_chunk_emit, dim3((unsigned)std::min<u64>(1024, R / 256 + 1)), dim3(256), 0, st, chunk_off, tok_off, R, dc, B.chunk_cap,
                          B.chunks, totals, c->h_totals); }   // the totals reach the host with this kernel
     HIPCHK(hipGetLastError());
     return TRP_OK;
