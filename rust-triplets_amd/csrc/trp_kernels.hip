@@ -799,10 +799,12 @@ __device__ inline void rec_lo_fill(u32* __restrict__ dst, u64 unit, u64 n_units,
 }
 // The offsets are checked on the way (offsets[0] = 0, non-decreasing, offsets[R] = N): a thread that finds them
 // wrong writes the batch's number `seq` to totals[9], which is never cleared - an older number means nothing.
-__global__ __launch_bounds__(256) void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW,
-                                                u32* __restrict__ rec_lo, u32* __restrict__ rec_lo_w,
-                                                u64* __restrict__ totals, u64 seq) {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+// (Every kernel of the path is a thin wrapper around a body function that takes its workgroup number as an
+// argument: k_small_batch runs the same bodies one after the other in a single workgroup.)
+__device__ __forceinline__ void rec_lo_body(u32 vb, const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW,
+                                            u32* __restrict__ rec_lo, u32* __restrict__ rec_lo_w,
+                                            u64* __restrict__ totals, u64 seq) {
+    const u64 r = (u64)vb * 256 + threadIdx.x;
     if (r < 16 && r != 9) totals[r] = 0;
     const bool live = r <= R;   // whole wavefronts stay: the long gaps are written together
     const bool has_lo = live && r > 0, has_hi = live && r < R;
@@ -811,6 +813,11 @@ __global__ __launch_bounds__(256) void k_rec_lo(const u64* __restrict__ offsets,
     // a thread beyond R owns nothing: an empty gap
     rec_lo_fill(rec_lo, TILE, nT, N, live ? has_lo : true, live ? lo : ~0ull, live ? has_hi : true, live ? hi : 0, (u32)r);
     rec_lo_fill(rec_lo_w, SUB, nW, N, live ? has_lo : true, live ? lo : ~0ull, live ? has_hi : true, live ? hi : 0, (u32)r);
+}
+__global__ __launch_bounds__(256) void k_rec_lo(const u64* __restrict__ offsets, u64 R, u64 N, u64 nT, u64 nW,
+                                                u32* __restrict__ rec_lo, u32* __restrict__ rec_lo_w,
+                                                u64* __restrict__ totals, u64 seq) {
+    rec_lo_body(blockIdx.x, offsets, R, N, nT, nW, rec_lo, rec_lo_w, totals, seq);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -944,18 +951,18 @@ struct SeedWave {
     S X[SEED_TPW];
 };
 
+struct SeedShared {
+    SeedWave shw[NT / 64];
+};
+// uni: the staged tables (stage_tables, complete before the call).
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, u64 nT,
-                                              u32 force_open, J* __restrict__ seedJ, S* __restrict__ seedS,
-                                              u32* __restrict__ open_count) {
-    __shared__ SeedWave shw[NT / 64];
-    __shared__ UniShared uni;
-    stage_tables(uni);
-    __syncthreads();
+__device__ __forceinline__ void seed_body(SeedShared& ssh, const UniShared& uni, u32 vb, const u8* __restrict__ bytes,
+                                          const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N,
+                                          u64 nB, u64 nT, u32 force_open, J* __restrict__ seedJ, S* __restrict__ seedS,
+                                          u32* __restrict__ open_count) {
     const int lane = threadIdx.x & 63;
-    SeedWave& sw = shw[threadIdx.x >> 6];
-    const u64 t0 = ((u64)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * SEED_TPW;
+    SeedWave& sw = ssh.shw[threadIdx.x >> 6];
+    const u64 t0 = ((u64)vb * (NT / 64) + (threadIdx.x >> 6)) * SEED_TPW;
     if (t0 >= nT) return;   // whole waves; no workgroup barrier below
     const UniTables ut = lds_tables(uni);
     u32 open_mask = 0;   // bit 2k: the back window of tile k is still open, bit 2k+1: its ahead window
@@ -1092,6 +1099,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void k_
         seedS[t0 + lane] = sw.X[lane];
     }
     if ((open_mask != 0 || force_open != 0) && lane == 0) *open_count = 1u;   // same value from every writer
+}
+template <bool NORMALIZE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void k_seed(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, u64 nT,
+                                              u32 force_open, J* __restrict__ seedJ, S* __restrict__ seedS,
+                                              u32* __restrict__ open_count) {
+    __shared__ SeedShared ssh;
+    __shared__ UniShared uni;
+    stage_tables(uni);
+    __syncthreads();
+    seed_body<NORMALIZE>(ssh, uni, blockIdx.x, bytes, offsets, rec_lo, R, N, nB, nT, force_open, seedJ, seedS, open_count);
 }
 
 // k_tile_carry: what enters tile t from the left (fold of the summaries back to the start of the
@@ -1252,18 +1270,17 @@ struct RatioArg {
 static_assert(sizeof(TileShared) >= 8 * TILE_BLOCKS * sizeof(u64), "mask arrays must fit in the byte image");
 static_assert(sizeof(MbScratch) * (NT / 64) <= sizeof(PlanWork), "the classifier's scratch must fit under the planning arrays");
 
+// uni: written here (stage_tables) before the first barrier.
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
-                                              const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
-                                              RatioArg ratio, PlanMem plan, u64* __restrict__ g3list, u64 g3cap,
-                                              u64* __restrict__ g3count,
-                                              u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
-                                              u32* __restrict__ tile_flags, u32 stop_after) {
-    __shared__ PlanShared sh;
-    __shared__ UniShared uni;
+__device__ __forceinline__ void plan_body(PlanShared& sh, UniShared& uni, u32 vb, const u8* __restrict__ bytes,
+                                          const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N,
+                                          u64 nB, const J* __restrict__ seedJ, const S* __restrict__ seedS,
+                                          const DevCfg& cfg, const RatioArg& ratio, const PlanMem& plan,
+                                          u64* __restrict__ g3list, u64 g3cap, u64* __restrict__ g3count,
+                                          u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
+                                          u32* __restrict__ tile_flags, u32 stop_after) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 t = blockIdx.x, tS = t * (u64)TILE;
+    const u64 t = vb, tS = t * (u64)TILE;
     const u64 b = t * (u64)TILE_BLOCKS + tid;
     {
         TileRegs regs;
@@ -1497,15 +1514,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
     }
 }
+template <bool NORMALIZE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6))) void k_plan(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                              const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB,
+                                              const J* __restrict__ seedJ, const S* __restrict__ seedS, DevCfg cfg,
+                                              RatioArg ratio, PlanMem plan, u64* __restrict__ g3list, u64 g3cap,
+                                              u64* __restrict__ g3count,
+                                              u32* __restrict__ tile_bytes, u32* __restrict__ tile_toks,
+                                              u32* __restrict__ tile_flags, u32 stop_after) {
+    __shared__ PlanShared sh;
+    __shared__ UniShared uni;
+    plan_body<NORMALIZE>(sh, uni, blockIdx.x, bytes, offsets, rec_lo, R, N, nB, seedJ, seedS, cfg, ratio, plan, g3list, g3cap,
+                         g3count, tile_bytes, tile_toks, tile_flags, stop_after);
+}
 
-__global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
-                                                      const u32* __restrict__ rec_lo, u64 R, u64 N,
-                                                      u64 nB, PlanMem plan, u32* __restrict__ tile_bytes,
-                                                      u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
-    __shared__ TileShared sh;
-    __shared__ RsShared rs;
+struct CountShared {
+    TileShared tile;
+    RsShared rs;
+};
+__device__ __forceinline__ void count_tokens_body(CountShared& csh, u32 vb, const u8* __restrict__ bytes,
+                                                  const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
+                                                  u64 N, u64 nB, const PlanMem& plan, u32* __restrict__ tile_bytes,
+                                                  u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
+    TileShared& sh = csh.tile;
+    RsShared& rs = csh.rs;
     const int tid = threadIdx.x, lane = tid & 63;
-    const u64 t = blockIdx.x, tS = t * (u64)TILE;
+    const u64 t = vb, tS = t * (u64)TILE;
     {
         TileRegs regs;
         RsFetch rf;
@@ -1541,6 +1575,13 @@ __global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ byte
             tile_flags[sub] = f;
         }
     }
+}
+__global__ __launch_bounds__(NT) void k_count_tokens(const u8* __restrict__ bytes, const u64* __restrict__ offsets,
+                                                      const u32* __restrict__ rec_lo, u64 R, u64 N,
+                                                      u64 nB, PlanMem plan, u32* __restrict__ tile_bytes,
+                                                      u32* __restrict__ tile_toks, u32* __restrict__ tile_flags) {
+    __shared__ CountShared csh;
+    count_tokens_body(csh, blockIdx.x, bytes, offsets, rec_lo, R, N, nB, plan, tile_bytes, tile_toks, tile_flags);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2162,24 +2203,32 @@ __device__ inline u32 g3_rows_lines(const u8* __restrict__ bytes, const u64* __r
 constexpr u32 G3_VIEW = G3_MAXW + 1;
 constexpr int G3S_LINES = 64 / G3_VIEW;             // lines per wavefront
 constexpr int G3S_STRIDE = 8 * (G3_VIEW + 1) + 1;   // u64 per line; odd, so that the lines spread over the banks
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_gate3_solve(const u8* __restrict__ bytes,
-                                                     const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
-                                                     PlanMem plan, const u64* __restrict__ list,
-                                                     const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
-                                                     u32* tile_toks, u64* __restrict__ totals, u8* __restrict__ scratch_text) {
-    __shared__ u64 masks[G3S_LINES * G3S_STRIDE];
-    __shared__ u64 pend[G3S_LINES];   // lines of the group that are too long for one lane: entries of the list
-    __shared__ u32 npend;
-    const int lane = threadIdx.x;
+// One wavefront's working space (the kernel's workgroups are single wavefronts, synchronised as such).
+struct G3SolveShared {
+    u64 masks[G3S_LINES * G3S_STRIDE];
+    u64 pend[G3S_LINES];   // lines of the group that are too long for one lane: entries of the list
+    u32 npend;
+};
+// vb / vgrid: this wavefront's number and the number of wavefronts that share the list.
+__device__ __forceinline__ void gate3_solve_body(G3SolveShared& gsh, u32 vb, u32 vgrid, const u8* __restrict__ bytes,
+                                                 const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R,
+                                                 u64 N, u64 nB, const DevCfg& cfg, const PlanMem& plan,
+                                                 const u64* __restrict__ list, const u64* __restrict__ mark_total, u64 cap,
+                                                 u32* tile_bytes, u32* tile_toks, u64* __restrict__ totals,
+                                                 u8* __restrict__ scratch_text) {
+    u64* const masks = gsh.masks;
+    u64* const pend = gsh.pend;
+    u32& npend = gsh.npend;
+    const int lane = threadIdx.x & 63;
     u64 n = *mark_total;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { totals[4] = n; totals[5] = n > cap ? 1 : 0; }
+    if (vb == 0 && lane == 0) { totals[4] = n; totals[5] = n > cap ? 1 : 0; }
     if (n > cap) n = cap;
     const int l = lane / (int)G3_VIEW, j = lane % (int)G3_VIEW;   // line of the group, block of its view
     u64* m = masks + (l < G3S_LINES ? l : 0) * G3S_STRIDE;        // eight arrays of G3_VIEW + 1 words
     const G3Masks gm = {m, m + (G3_VIEW + 1), m + 2 * (G3_VIEW + 1), m + 3 * (G3_VIEW + 1), m + 4 * (G3_VIEW + 1),
                         m + 5 * (G3_VIEW + 1), m + 6 * (G3_VIEW + 1), m + 7 * (G3_VIEW + 1)};
     const UniTables ut = dev_tables();
-    for (u64 i0 = (u64)blockIdx.x * G3S_LINES; i0 < n; i0 += (u64)gridDim.x * G3S_LINES) {   // uniform
+    for (u64 i0 = (u64)vb * G3S_LINES; i0 < n; i0 += (u64)vgrid * G3S_LINES) {   // uniform
         const u64 i = i0 + (u64)l;
         const bool have = l < G3S_LINES && i < n;
         u64 p = 0;
@@ -2212,7 +2261,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             gm.ws[j] = c.ws; gm.pipe[j] = c.pipe; gm.dig[j] = c.dig; gm.alp[j] = c.alp; gm.ls[j] = LS;
             gm.G[j] = 0; gm.gPSP[j] = 0; gm.gPNL[j] = 0;
         }
-        __syncthreads();   // (one wavefront per workgroup) the masks of a line are written by five lanes and read by the first of them
+        wave_lds_sync();   // the masks of a line are written by five lanes and read by the first of them
         if (have && j == 0) {
             const u64 view0 = w0 * 64;
             const u32 cend = (N - view0 <= (u64)G3_VIEW * 64) ? (u32)(N - view0) : 0xFFFFFFFFu;
@@ -2239,7 +2288,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 pend[atomicAdd(&npend, 1u)] = list[i];
             }
         }
-        __syncthreads();   // the line's lane has read the masks before the next group overwrites them
+        wave_lds_sync();   // the line's lane has read the masks before the next group overwrites them
         // the long lines of the group, one after the other, by the whole wavefront (up to 4 KiB, then up to 16 KiB);
         // what is longer still is walked by one lane
         const u32 np = npend;
@@ -2258,8 +2307,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 }
             }
         }
-        __syncthreads();   // npend and pend are free again
+        wave_lds_sync();   // npend and pend are free again
     }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_gate3_solve(const u8* __restrict__ bytes,
+                                                     const u64* __restrict__ offsets, const u32* __restrict__ rec_lo, u64 R, u64 N, u64 nB, DevCfg cfg,
+                                                     PlanMem plan, const u64* __restrict__ list,
+                                                     const u64* __restrict__ mark_total, u64 cap, u32* tile_bytes,
+                                                     u32* tile_toks, u64* __restrict__ totals, u8* __restrict__ scratch_text) {
+    __shared__ G3SolveShared gsh;
+    gate3_solve_body(gsh, blockIdx.x, gridDim.x, bytes, offsets, rec_lo, R, N, nB, cfg, plan, list, mark_total, cap, tile_bytes,
+                     tile_toks, totals, scratch_text);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2424,8 +2482,7 @@ __global__ __launch_bounds__(NT) void k_scan_reduce_gen(Gen gen, u64 n, u64* __r
     }
 }
 template <class Gen>
-__global__ __launch_bounds__(NT) void k_scan_small_gen(Gen gen, u64 n, u64* __restrict__ out) {
-    __shared__ u64 smem[NT / 64];
+__device__ __forceinline__ void scan_small_body(u64* smem, const Gen& gen, u64 n, u64* __restrict__ out) {
     const typename Gen::State st = gen.begin();
     u64 carry = 0;
     for (u64 base = 0; base < n; base += NT) {   // uniform
@@ -2440,6 +2497,11 @@ __global__ __launch_bounds__(NT) void k_scan_small_gen(Gen gen, u64 n, u64* __re
         out[n] = carry;
         gen.once();
     }
+}
+template <class Gen>
+__global__ __launch_bounds__(NT) void k_scan_small_gen(Gen gen, u64 n, u64* __restrict__ out) {
+    __shared__ u64 smem[NT / 64];
+    scan_small_body(smem, gen, n, out);
 }
 // k_scan_final with the workgroup's base summed from the (unscanned) partial sums of the workgroups before it
 __global__ __launch_bounds__(NT) void k_scan_final_sum(const u64* __restrict__ in, u64 n, const u64* __restrict__ partial,
@@ -2639,16 +2701,14 @@ __device__ inline u32 below32(u32 j) { return j >= 32 ? ~0u : ((1u << j) - 1u); 
 // token plane in the plan.
 constexpr int EMIT_WAVES = 4;
 template <bool PASSTHROUGH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8))) void k_emit(const u8* __restrict__ bytes,
-                                              const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
-                                              u64 N, u64 nB, u64 nW, PlanMem plan,
-                                              const u64* __restrict__ tile_base, u8* __restrict__ denoised,
-                                              u32* __restrict__ tok_start, u32* __restrict__ tok_len,
-                                              u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
-    __shared__ EmitShared shw[WAVES];
+__device__ __forceinline__ void emit_body(EmitShared* shw, u32 vb, const u8* __restrict__ bytes,
+                                          const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 N,
+                                          u64 nB, u64 nW, const PlanMem& plan, const u64* __restrict__ tile_base,
+                                          u8* __restrict__ denoised, u32* __restrict__ tok_start, u32* __restrict__ tok_len,
+                                          u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
     EmitShared& sh = shw[threadIdx.x >> 6];
     const int tid = threadIdx.x & 63;   // = lane
-    const u64 t = (u64)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const u64 t = (u64)vb * WAVES + (threadIdx.x >> 6);
     if (t >= nW) return;
     SubRs& srs = *reinterpret_cast<SubRs*>(sh.out);
     EmitIn in;
@@ -2913,17 +2973,29 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8)))
         }
     }
 }
+template <bool PASSTHROUGH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8))) void k_emit(const u8* __restrict__ bytes,
+                                              const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
+                                              u64 N, u64 nB, u64 nW, PlanMem plan,
+                                              const u64* __restrict__ tile_base, u8* __restrict__ denoised,
+                                              u32* __restrict__ tok_start, u32* __restrict__ tok_len,
+                                              u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
+    __shared__ EmitShared shw[WAVES];
+    emit_body<PASSTHROUGH, WAVES>(shw, blockIdx.x, bytes, offsets, rec_lo_w, R, N, nB, nW, plan, tile_base, denoised, tok_start,
+                                  tok_len, den_off, tok_off, stop_after);
+}
 
 // One lane per record (wavefronts stride over the records): a record's first CHUNK_INLINE descriptors are
 // written by its lane, the rest of a record with many windows by the whole wavefront.
 constexpr u32 CHUNK_INLINE = 4;
 // The last kernel of a batch: its first thread also copies the batch's totals and flags (totals[0..9]) into the
 // page-locked host words `host_totals`, which spares a copy command behind the kernels.
-__global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off, u64 R, DevCfg cfg,
-                             u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals,
-                             u64* __restrict__ host_totals) {
+__device__ __forceinline__ void chunk_emit_body(u32 vb, u32 vgrid, const u64* __restrict__ chunk_off,
+                                                const u64* __restrict__ tok_off, u64 R, const DevCfg& cfg, u64 capacity,
+                                                ChunkDesc* __restrict__ chunks, u64* __restrict__ totals,
+                                                u64* __restrict__ host_totals) {
     const u64 C = chunk_off[R];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (vb == 0 && threadIdx.x == 0) {
         totals[2] = C;
         totals[3] = C > capacity ? 1 : 0;
         if (host_totals) {
@@ -2933,7 +3005,7 @@ __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __res
     }
     if (C > capacity) return;
     const int lane = threadIdx.x & 63;
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u64 wave = ((u64)vb * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)vgrid * blockDim.x) >> 6;
     for (u64 rb = wave * 64; rb < R; rb += nwaves * 64) {   // uniform
         const u64 r = rb + (u64)lane;
         u64 n = 0, T = 0, base = 0;
@@ -2951,6 +3023,114 @@ __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __res
             for (u64 i = CHUNK_INLINE + (u64)lane; i < nn; i += 64) chunks[bb + i] = chunk_at(TT, i, (u32)(rb + (u64)L), cfg);
         }
     }
+}
+__global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off, u64 R, DevCfg cfg,
+                             u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals,
+                             u64* __restrict__ host_totals) {
+    chunk_emit_body(blockIdx.x, gridDim.x, chunk_off, tok_off, R, cfg, capacity, chunks, totals, host_totals);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_small_batch: the whole path in one launch, for batches of a few tiles
+// ---------------------------------------------------------------------------------------------------
+// A batch of a few kilobytes is bound by the number of dependent launches (eight of them, each a few
+// microseconds, for microseconds of work).  Up to SMALL_MAX_TILES tiles and SMALL_MAX_RECORDS records are
+// therefore handled by ONE workgroup that runs the bodies of the kernels above one after the other, with a
+// workgroup barrier where the full path has a kernel boundary.  Same code, same arrays, same results; when the
+// tile seeds cannot be settled from the windows next to the tiles the batch says so in its totals exactly as the
+// full path does, and the host runs it again there.
+constexpr u64 SMALL_MAX_TILES = 2;        // 32 KiB of text: one workgroup takes ~13 us a tile, the kernel sequence ~50 us in all
+constexpr u64 SMALL_MAX_RECORDS = 4096;
+struct SmallArgs {
+    const u8* bytes;
+    const u64* offsets;
+    u64 R, N;
+    DevCfg cfg;
+    RatioArg ratio;
+    u32 force_open;
+    // working arrays (see PathBufs)
+    u32 *rec_lo, *rec_lo_w;
+    J* seedJ;
+    S* seedS;
+    void* plan;
+    u64* g3list;
+    u64 g3cap;
+    u32 *tile_bytes, *tile_toks, *tile_flags;
+    u64 *packed, *tile_base, *counts, *totals;
+    // results
+    u8* denoised;
+    u64 *den_off, *tok_off, *chunk_off;
+    u8* dropped;
+    u32 *tok_start, *tok_len;
+    ChunkDesc* chunks;
+    u64 chunk_cap;
+    u64* host_totals;
+    u64 seq;
+};
+union SmallShared {
+    SeedShared seed;
+    PlanShared plan;
+    CountShared count;
+    EmitShared emit[EMIT_WAVES];
+    G3SolveShared g3[NT / 64];
+    u64 scan[NT / 64];
+};
+static_assert(EMIT_WAVES == NT / 64, "the emit body takes one sub-tile per wavefront of the workgroup");
+
+template <int MODE>   // 0: denoiser, 1: normalize_inline_whitespace, 2: denoiser off (pass-through)
+__global__ __launch_bounds__(NT) void k_small_batch(SmallArgs a) {
+    __shared__ SmallShared sh;
+    __shared__ UniShared uni;
+    const u64 R = a.R, N = a.N;
+    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
+    const PlanMem plan = plan_view(a.plan, nB);
+    const int wave = threadIdx.x >> 6;
+    for (u32 vb = 0; (u64)vb * NT <= R; vb++)
+        rec_lo_body(vb, a.offsets, R, N, nT, nW, a.rec_lo, a.rec_lo_w, a.totals, a.seq);
+    stage_tables(uni);
+    __syncthreads();
+    if (nT) {   // uniform
+        if (MODE != 2) {
+            u32* const open_count = reinterpret_cast<u32*>(a.totals + 8);   // zeroed with the totals
+            for (u32 vb = 0; (u64)vb * SEED_TPW * (NT / 64) < nT; vb++)   // (a wavefront shares nothing with the others)
+                seed_body<MODE == 1>(sh.seed, uni, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, nT, a.force_open, a.seedJ,
+                                     a.seedS, open_count);
+            __syncthreads();
+            for (u32 vb = 0; vb < nT; vb++) {
+                plan_body<MODE == 1>(sh.plan, uni, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, a.seedJ, a.seedS, a.cfg, a.ratio,
+                                     plan, a.g3list, a.g3cap, a.totals + 6, a.tile_bytes, a.tile_toks, a.tile_flags, 0u);
+                __syncthreads();
+            }
+            gate3_solve_body(sh.g3[wave], (u32)wave, NT / 64, a.bytes, a.offsets, a.rec_lo, R, N, nB, a.cfg, plan, a.g3list,
+                             a.totals + 6, a.g3cap, a.tile_bytes, a.tile_toks, a.totals, a.denoised);
+        } else {
+            for (u32 vb = 0; vb < nT; vb++) {
+                count_tokens_body(sh.count, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, plan, a.tile_bytes, a.tile_toks,
+                                  a.tile_flags);
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        {
+            const GenTiles gen = {a.tile_bytes, a.tile_toks, a.tile_flags, a.packed};
+            scan_small_body(sh.scan, gen, nW, a.tile_base);
+        }
+        __syncthreads();
+        for (u32 vb = 0; (u64)vb * EMIT_WAVES < nW; vb++)   // (wavefronts are independent of each other here too)
+            emit_body<MODE == 2, EMIT_WAVES>(sh.emit, vb, a.bytes, a.offsets, a.rec_lo_w, R, N, nB, nW, plan, a.tile_base,
+                                             MODE == 2 ? (u8*)nullptr : a.denoised, a.tok_start, a.tok_len, a.den_off,
+                                             a.tok_off, 0u);
+        __syncthreads();
+    }
+    {
+        GenChunkCounts gen;
+        gen.tile_base = a.tile_base; gen.nW = nW; gen.rec_lo_w = a.rec_lo_w; gen.R = R; gen.N = N;
+        gen.passthrough = MODE == 2 ? 1 : 0; gen.cfg = a.cfg;
+        gen.den_off = a.den_off; gen.tok_off = a.tok_off; gen.totals = a.totals; gen.counts = a.counts; gen.dropped = a.dropped;
+        scan_small_body(sh.scan, gen, R, a.chunk_off);
+    }
+    __syncthreads();
+    chunk_emit_body(0u, 1u, a.chunk_off, a.tok_off, R, a.cfg, a.chunk_cap, a.chunks, a.totals, a.host_totals);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3235,6 +3415,9 @@ struct trp_ctx {
     // Test aid: TRIPLETS_AMD_FORCE_SUMMARY=1 in the environment when the context is created makes every
     // batch take the per-tile-summary path for the tile seeds (normally only batches that k_seed cannot settle).
     u32 force_summary = 0;
+    // Test aid: TRIPLETS_AMD_NO_SMALL=1 in the environment when the context is created keeps batches of a few tiles
+    // on the full kernel sequence (normally they take the single launch of k_small_batch).
+    bool no_small = false;
     // The summary kernels (k_summary, k_tile_carry_near, k_tile_carry) are launched only while batches need them:
     // a batch whose tiles k_seed could not all settle is run again with them, and so are the batches after it
     // until one comes along that k_seed settles alone.
@@ -3385,6 +3568,7 @@ static int create_ctx(int device, hipStream_t stream, bool own, trp_ctx** out) {
     c->scratch_ptr = sp;
     { const char* e2 = getenv("TRIPLETS_AMD_FORCE_SUMMARY"); c->force_summary = (e2 && atoi(e2)) ? 1u : 0u; }
     c->summary_path = c->force_summary != 0;
+    { const char* e3 = getenv("TRIPLETS_AMD_NO_SMALL"); c->no_small = e3 && atoi(e3); }
     c->device = device;
     c->owns_stream = own;
     c->stream = stream;
@@ -3521,6 +3705,26 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
             c->ratio_bits = bits;
             c->ratio_valid = true;
         }
+    }
+    if (nT <= SMALL_MAX_TILES && R <= SMALL_MAX_RECORDS && !with_summary && !c->force_summary && !c->no_small &&
+        !c->plan_stop() && !c->emit_stop()) {
+        Prof pr(c, "k_small_batch");
+        SmallArgs a;
+        memset(&a, 0, sizeof(a));
+        a.bytes = d_bytes; a.offsets = d_offsets; a.R = R; a.N = N;
+        a.cfg = dc; a.ratio = c->ratio_arg; a.force_open = 0;
+        a.rec_lo = B.rec_lo; a.rec_lo_w = B.rec_lo_w; a.seedJ = B.seedJ; a.seedS = B.seedS; a.plan = B.plan;
+        a.g3list = B.g3list; a.g3cap = B.g3_cap;
+        a.tile_bytes = B.tile_bytes; a.tile_toks = B.tile_toks; a.tile_flags = B.tile_flags;
+        a.packed = B.packed; a.tile_base = B.tile_base; a.counts = B.counts; a.totals = B.totals;
+        a.denoised = B.denoised; a.den_off = B.den_off; a.tok_off = B.tok_off; a.chunk_off = B.chunk_off;
+        a.dropped = B.dropped; a.tok_start = B.tok_start; a.tok_len = B.tok_len; a.chunks = B.chunks;
+        a.chunk_cap = B.chunk_cap; a.host_totals = c->h_totals; a.seq = B.seq;
+        if (pass) hipLaunchKernelGGL(k_small_batch<2>, dim3(1), dim3(NT), 0, st, a);
+        else if (dc.normalize) hipLaunchKernelGGL(k_small_batch<1>, dim3(1), dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL(k_small_batch<0>, dim3(1), dim3(NT), 0, st, a);
+        HIPCHK(hipGetLastError());
+        return TRP_OK;
     }
     {
         Prof pr(c, "k_rec_lo");   // also clears the totals and counters
