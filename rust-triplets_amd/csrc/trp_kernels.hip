@@ -3040,6 +3040,9 @@ __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __res
 // tile seeds cannot be settled from the windows next to the tiles the batch says so in its totals exactly as the
 // full path does, and the host runs it again there.
 constexpr u64 SMALL_MAX_TILES = 2;        // 32 KiB of text: one workgroup takes ~13 us a tile, the kernel sequence ~50 us in all
+// A batch that comes from host memory and goes back there saves the copy commands on both sides as well (they cost
+// more than the kernels at these sizes), which pays up to more tiles.
+constexpr u64 SMALL_HOST_MAX_TILES = 4;   // 64 KiB of text (121 us instead of 180 us for the whole call there)
 constexpr u64 SMALL_MAX_RECORDS = 4096;
 struct SmallArgs {
     const u8* bytes;
@@ -3066,7 +3069,45 @@ struct SmallArgs {
     u64 chunk_cap;
     u64* host_totals;
     u64 seq;
+    // A batch that comes from host memory (null otherwise): its text and offsets lie in page-locked host memory and
+    // are first copied to `bytes` / `offsets` (stage_bytes / stage_offsets are the same arrays, writable); at the
+    // end the results are gathered into one page-locked block (pack_layout) when they fit.
+    const u8* src_bytes;
+    const u64* src_offsets;
+    u8* stage_bytes;
+    u64* stage_offsets;
+    u8* host_out;
+    u64 host_out_cap;
+    u32 outputs;
 };
+// Where the result arrays of a small host batch lie in the page-locked block, every array on a 16-byte boundary.
+struct PackLayout {
+    u64 den_off, tok_off, chunk_off, chunks, tok_start, tok_len, denoised, dropped, total;
+};
+__host__ __device__ inline PackLayout pack_layout(u64 R, u64 n_den, u64 n_tok, u64 n_chunks, u32 outputs) {
+    PackLayout L;
+    u64 p = 0;
+    auto take = [&p](u64 bytes) { const u64 at = p; p += (bytes + 15) & ~(u64)15; return at; };
+    L.den_off = take((R + 1) * sizeof(u64));
+    L.tok_off = take((R + 1) * sizeof(u64));
+    L.chunk_off = take((R + 1) * sizeof(u64));
+    L.chunks = take((outputs & TRP_OUT_CHUNKS) ? n_chunks * sizeof(ChunkDesc) : 0);
+    L.tok_start = take((outputs & TRP_OUT_TOKENS) ? n_tok * sizeof(u32) : 0);
+    L.tok_len = take((outputs & TRP_OUT_TOKENS) ? n_tok * sizeof(u32) : 0);
+    L.denoised = take((outputs & TRP_OUT_TEXT) ? n_den : 0);
+    L.dropped = take(R);
+    L.total = p;
+    return L;
+}
+// n bytes from a 16-byte aligned device array to a 16-byte aligned place in host memory, by the whole workgroup.
+__device__ inline void pack_copy(u8* __restrict__ dst, const void* __restrict__ src_, u64 n) {
+    const u8* src = reinterpret_cast<const u8*>(src_);
+    const u64 q = n >> 4;
+    for (u64 i = threadIdx.x; i < q; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (u64 i = (q << 4) + threadIdx.x; i < n; i += NT) dst[i] = src[i];
+}
+constexpr u64 SMALL_OUT_CAP = (u64)1 << 20;   // page-locked block for the results of a small host batch
+constexpr u64 SMALL_IN_CAP = SMALL_HOST_MAX_TILES * TILE + 64 + (SMALL_MAX_RECORDS + 1) * sizeof(u64);
 union SmallShared {
     SeedShared seed;
     PlanShared plan;
@@ -3085,6 +3126,12 @@ __global__ __launch_bounds__(NT) void k_small_batch(SmallArgs a) {
     const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
     const PlanMem plan = plan_view(a.plan, nB);
     const int wave = threadIdx.x >> 6;
+    if (a.src_offsets) {   // uniform: the batch comes from page-locked host memory (the block has slack behind the text)
+        for (u64 i = threadIdx.x; i * 16 < N; i += NT)
+            reinterpret_cast<uint4*>(a.stage_bytes)[i] = reinterpret_cast<const uint4*>(a.src_bytes)[i];
+        for (u64 i = threadIdx.x; i <= R; i += NT) a.stage_offsets[i] = a.src_offsets[i];
+        __syncthreads();
+    }
     for (u32 vb = 0; (u64)vb * NT <= R; vb++)
         rec_lo_body(vb, a.offsets, R, N, nT, nW, a.rec_lo, a.rec_lo_w, a.totals, a.seq);
     stage_tables(uni);
@@ -3131,6 +3178,28 @@ __global__ __launch_bounds__(NT) void k_small_batch(SmallArgs a) {
     }
     __syncthreads();
     chunk_emit_body(0u, 1u, a.chunk_off, a.tok_off, R, a.cfg, a.chunk_cap, a.chunks, a.totals, a.host_totals);
+    if (a.host_out) {   // uniform
+        __syncthreads();
+        // nothing to gather from a batch that the host will run again (open tiles, a list or the descriptor array too
+        // small) or reject (offsets)
+        const u64 n_den = a.totals[0], n_tok = a.totals[1], C = a.chunk_off[R];
+        const bool again = a.totals[5] != 0 || (u32)a.totals[8] != 0 || C > a.chunk_cap || a.totals[9] == a.seq;
+        const PackLayout L = pack_layout(R, n_den, n_tok, C, a.outputs);
+        if (!again && L.total <= a.host_out_cap) {
+            u8* const o = a.host_out;
+            pack_copy(o + L.den_off, a.den_off, (R + 1) * sizeof(u64));
+            pack_copy(o + L.tok_off, a.tok_off, (R + 1) * sizeof(u64));
+            pack_copy(o + L.chunk_off, a.chunk_off, (R + 1) * sizeof(u64));
+            if (a.outputs & TRP_OUT_CHUNKS) pack_copy(o + L.chunks, a.chunks, C * sizeof(ChunkDesc));
+            if (a.outputs & TRP_OUT_TOKENS) {
+                pack_copy(o + L.tok_start, a.tok_start, n_tok * sizeof(u32));
+                pack_copy(o + L.tok_len, a.tok_len, n_tok * sizeof(u32));
+            }
+            if (a.outputs & TRP_OUT_TEXT) pack_copy(o + L.denoised, MODE == 2 ? a.bytes : a.denoised, n_den);
+            pack_copy(o + L.dropped, a.dropped, R);
+            if (threadIdx.x == 0) a.host_totals[10] = a.seq;   // "gathered": read by the host once the kernel has ended
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3399,6 +3468,16 @@ struct trp_ctx {
     DevBuf heads;                       // head-of-record / chunk-body descriptors (trp_head_tokens_text_device, trp_chunk_bodies_device)
     DevBuf sel;                         // caller's selection arrays (chunk indices + budgets, document offsets)
     u64* h_totals = nullptr;            // pinned
+    // Small batches from host memory: text and offsets go into the page-locked block h_in, from where the single
+    // launch fetches them itself, and the results come back gathered in the page-locked block h_out (both made at
+    // the first such batch).  small_io is set around the device call of such a batch only.
+    u8* h_in = nullptr;
+    u8* h_out = nullptr;
+    struct SmallIO {
+        bool on = false;
+        bool gather = false;
+        u32 outputs = 0;
+    } small_io;
     unsigned char* scratch_ptr = nullptr;   // this GPU's copy of the fixed scratch array (see scratch_of_device)
     // the digit-ratio test as a table (ratio_table_fill), kept for the max_digit_ratio it was made for
     RatioArg ratio_arg = {};
@@ -3618,6 +3697,8 @@ void trp_destroy(trp_ctx* c) {
                       &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list, &c->sel};
     for (DevBuf* b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -3685,6 +3766,12 @@ static u64 token_bound(u64 N, u64 R) { return (N + std::min<u64>(R, N)) / 2 + 4;
 
 // Enqueues the kernels of the whole path for one batch on `st`; nothing is allocated here.  `c` supplies the
 // profiling switches only.
+// Whether a batch of N bytes in R records takes the single launch when the context is not on the summary path.
+static bool small_batch_ok(const trp_ctx* c, u64 N, u64 R, u64 max_tiles = SMALL_MAX_TILES) {
+    return (N + TILE - 1) / TILE <= max_tiles && R <= SMALL_MAX_RECORDS && !c->force_summary && !c->no_small &&
+           !c->plan_stop() && !c->emit_stop();
+}
+
 static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uint8_t* d_bytes, const uint64_t* d_offsets,
                         uint64_t R, uint64_t N, const DevCfg& dc, bool with_summary) {
     int rc;
@@ -3706,8 +3793,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
             c->ratio_valid = true;
         }
     }
-    if (nT <= SMALL_MAX_TILES && R <= SMALL_MAX_RECORDS && !with_summary && !c->force_summary && !c->no_small &&
-        !c->plan_stop() && !c->emit_stop()) {
+    if (small_batch_ok(c, N, R, c->small_io.on ? SMALL_HOST_MAX_TILES : SMALL_MAX_TILES) && !with_summary) {
         Prof pr(c, "k_small_batch");
         SmallArgs a;
         memset(&a, 0, sizeof(a));
@@ -3720,6 +3806,13 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
         a.denoised = B.denoised; a.den_off = B.den_off; a.tok_off = B.tok_off; a.chunk_off = B.chunk_off;
         a.dropped = B.dropped; a.tok_start = B.tok_start; a.tok_len = B.tok_len; a.chunks = B.chunks;
         a.chunk_cap = B.chunk_cap; a.host_totals = c->h_totals; a.seq = B.seq;
+        if (c->small_io.on) {
+            a.src_bytes = c->h_in;
+            a.src_offsets = reinterpret_cast<const u64*>(c->h_in + SMALL_HOST_MAX_TILES * TILE + 64);
+            a.stage_bytes = const_cast<u8*>(d_bytes);          // the context's own in_bytes / in_offsets
+            a.stage_offsets = const_cast<u64*>(d_offsets);
+            if (c->small_io.gather) { a.host_out = c->h_out; a.host_out_cap = SMALL_OUT_CAP; a.outputs = c->small_io.outputs; }
+        }
         if (pass) hipLaunchKernelGGL(k_small_batch<2>, dim3(1), dim3(NT), 0, st, a);
         else if (dc.normalize) hipLaunchKernelGGL(k_small_batch<1>, dim3(1), dim3(NT), 0, st, a);
         else hipLaunchKernelGGL(k_small_batch<0>, dim3(1), dim3(NT), 0, st, a);
@@ -4477,6 +4570,35 @@ static int run_host_pipelined(trp_ctx* c, const uint8_t* bytes, const uint64_t* 
     return TRP_OK;
 }
 
+// A small batch from host memory onto the device and through the path in ONE launch: text and offsets are put
+// into the context's page-locked block, the kernel fetches them from there (no copy commands in front of it) and,
+// with `gather`, leaves the selected result arrays in the other page-locked block (no copy commands behind it
+// either).  *gathered tells whether it did: not when the batch had to be run again by the kernel sequence or the
+// arrays exceed the block; the device arrays in *d are valid either way.  Call only when small_host_ok() holds.
+static bool small_host_ok(const trp_ctx* c, u64 N, u64 R) {
+    return small_batch_ok(c, N, R, SMALL_HOST_MAX_TILES) && !c->summary_path;
+}
+static int run_small_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, uint64_t N,
+                          const DevCfg& dc, bool gather, uint32_t outputs, trp_result* d, bool* gathered) {
+    int rc;
+    *gathered = false;
+    if (!c->h_in) HIPCHK(hipHostMalloc((void**)&c->h_in, SMALL_IN_CAP, hipHostMallocDefault));
+    if (gather && !c->h_out) HIPCHK(hipHostMalloc((void**)&c->h_out, SMALL_OUT_CAP, hipHostMallocDefault));
+    if ((rc = c->in_bytes.ensure(N + 64))) return rc;
+    if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
+    if (N) memcpy(c->h_in, bytes, N);
+    memcpy(c->h_in + SMALL_HOST_MAX_TILES * TILE + 64, offsets, (R + 1) * sizeof(u64));
+    c->h_totals[10] = 0;
+    c->small_io.on = true;
+    c->small_io.gather = gather;
+    c->small_io.outputs = outputs;
+    rc = run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, d);
+    c->small_io = trp_ctx::SmallIO();
+    if (rc) return rc;
+    *gathered = gather && c->h_totals[10] != 0;
+    return TRP_OK;
+}
+
 static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
                     trp_result* out, uint32_t outputs = TRP_OUT_ALL, trp_chunk_text* ctext = nullptr) {
     if (!c || !out || !offsets) return fail(TRP_E_ARG, "null argument");
@@ -4493,19 +4615,28 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
     if (N >= PIPE_MIN_BYTES && R >= 2 && dc.denoise_enabled && !(no_pipe && atoi(no_pipe)))
         return run_host_pipelined(c, bytes, offsets, R, dc, outputs, out, ctext);
     int rc;
-    if ((rc = c->in_bytes.ensure(N + 64))) return rc;
-    if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
-    if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     trp_result d;
-    rc = run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, &d);
-    if (rc) return rc;
+    bool gathered = false;
+    if (small_host_ok(c, N, R)) {
+        if ((rc = run_small_host(c, bytes, offsets, R, N, dc, true, outputs, &d, &gathered))) return rc;
+    } else {
+        if ((rc = c->in_bytes.ensure(N + 64))) return rc;
+        if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
+        if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        if ((rc = run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, &d))) return rc;
+    }
     memset(out, 0, sizeof(*out));
     out->n_records = R; out->n_denoised = d.n_denoised; out->n_tokens = d.n_tokens; out->n_chunks = d.n_chunks;
-    auto grab = [&](void** dst, const void* src, size_t bytes_) -> int {
+    const PackLayout L = pack_layout(R, d.n_denoised, d.n_tokens, d.n_chunks, outputs);
+    // one result array: out of the gathered block when the kernel has filled it (`at` = its place there), else by a
+    // copy command from the device array
+    auto grab = [&](void** dst, const void* src, size_t bytes_, u64 at = ~(u64)0) -> int {
         *dst = host_pool().alloc(bytes_);
         if (!*dst) return fail(TRP_E_ARG, "out of host memory");
-        if (bytes_) {
+        if (bytes_ && gathered && at != ~(u64)0) {
+            memcpy(*dst, c->h_out + at, bytes_);
+        } else if (bytes_) {
             hipError_t e = hipMemcpyAsync(*dst, src, bytes_, hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) return fail(TRP_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
         }
@@ -4518,14 +4649,14 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         if (ctext) { host_pool().release(ctext->text); host_pool().release(ctext->offsets); memset(ctext, 0, sizeof(*ctext)); }
         return code;
     };
-    if ((outputs & TRP_OUT_TEXT) && (rc = grab((void**)&out->denoised, d.denoised, d.n_denoised))) return fail_free(rc);
-    if ((rc = grab((void**)&out->denoised_offsets, d.denoised_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
-    if ((rc = grab((void**)&out->dropped, d.dropped, R))) return fail_free(rc);
-    if ((outputs & TRP_OUT_TOKENS) && (rc = grab((void**)&out->tok_start, d.tok_start, d.n_tokens * sizeof(u32)))) return fail_free(rc);
-    if ((outputs & TRP_OUT_TOKENS) && (rc = grab((void**)&out->tok_len, d.tok_len, d.n_tokens * sizeof(u32)))) return fail_free(rc);
-    if ((rc = grab((void**)&out->tok_offsets, d.tok_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
-    if ((outputs & TRP_OUT_CHUNKS) && (rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk)))) return fail_free(rc);
-    if ((rc = grab((void**)&out->chunk_offsets, d.chunk_offsets, (R + 1) * sizeof(u64)))) return fail_free(rc);
+    if ((outputs & TRP_OUT_TEXT) && (rc = grab((void**)&out->denoised, d.denoised, d.n_denoised, L.denoised))) return fail_free(rc);
+    if ((rc = grab((void**)&out->denoised_offsets, d.denoised_offsets, (R + 1) * sizeof(u64), L.den_off))) return fail_free(rc);
+    if ((rc = grab((void**)&out->dropped, d.dropped, R, L.dropped))) return fail_free(rc);
+    if ((outputs & TRP_OUT_TOKENS) && (rc = grab((void**)&out->tok_start, d.tok_start, d.n_tokens * sizeof(u32), L.tok_start))) return fail_free(rc);
+    if ((outputs & TRP_OUT_TOKENS) && (rc = grab((void**)&out->tok_len, d.tok_len, d.n_tokens * sizeof(u32), L.tok_len))) return fail_free(rc);
+    if ((rc = grab((void**)&out->tok_offsets, d.tok_offsets, (R + 1) * sizeof(u64), L.tok_off))) return fail_free(rc);
+    if ((outputs & TRP_OUT_CHUNKS) && (rc = grab((void**)&out->chunks, d.chunks, d.n_chunks * sizeof(trp_chunk), L.chunks))) return fail_free(rc);
+    if ((rc = grab((void**)&out->chunk_offsets, d.chunk_offsets, (R + 1) * sizeof(u64), L.chunk_off))) return fail_free(rc);
     if (outputs & TRP_OUT_CHUNK_TEXT) {
         uint8_t* d_ct = nullptr;
         uint64_t* d_cto = nullptr;
@@ -4574,6 +4705,10 @@ static int stage_and_run(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
         if (offsets[r + 1] < offsets[r]) return fail(TRP_E_ARG, "offsets must be non-decreasing");
     HIPCHK(hipSetDevice(c->device));
     int rc;
+    if (small_host_ok(c, N, R)) {
+        bool gathered;
+        return run_small_host(c, bytes, offsets, R, N, dc, false, 0, d, &gathered);
+    }
     if ((rc = c->in_bytes.ensure(N + 64))) return rc;
     if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
     if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));

@@ -14,7 +14,7 @@ and a GPU, and raises TripletsAmdError otherwise.
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -40,6 +40,39 @@ class _Config(C.Structure):
 class _Chunk(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("record", "kind", "index", "overlap", "span", "tok_begin", "tok_end", "reserved")]
+
+
+def _copy_out(ptr: int, nbytes: int, dtype) -> np.ndarray:
+    """One copy of `nbytes` of library-owned host memory at `ptr` as a numpy array the caller owns."""
+    return np.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=dtype).copy()
+
+
+class _Owner:
+    """Frees one library-owned host array when the last numpy view of it goes away."""
+    __slots__ = ("_free", "_ptr")
+
+    def __init__(self, free, ptr):
+        self._free, self._ptr = free, ptr
+
+    def __del__(self):
+        try:
+            self._free(self._ptr)
+        except Exception:
+            pass
+
+
+_ADOPT_MIN = 64 << 10
+
+
+def _take_out(lib, ptr: int, nbytes: int, dtype) -> Tuple[np.ndarray, bool]:
+    """A library-owned host array as a numpy array: arrays of 64 KiB and more are handed over as they are (the
+    array's base keeps the memory and gives it back with trp_free when collected; True is returned and the caller
+    must not free `ptr`), smaller ones are copied."""
+    if nbytes < _ADOPT_MIN:
+        return _copy_out(ptr, nbytes, dtype), False
+    buf = (C.c_ubyte * nbytes).from_address(ptr)
+    buf._owner = _Owner(lib.trp_free, ptr)
+    return np.frombuffer(buf, dtype=dtype), True
 
 
 class _Result(C.Structure):
@@ -396,21 +429,25 @@ class Context:
         return self._L.trp_stream(self._h) or 0
 
     def _host_result(self, res, R) -> "BatchResult":
-        def arr(ptr, n, dt):
+        def arr(field, n, dt):
             dt = np.dtype(dt)
+            ptr = getattr(res, field)
             if not n or not ptr:
                 return np.zeros(0, dtype=dt)
-            return np.frombuffer(C.string_at(ptr, int(n) * dt.itemsize), dtype=dt).copy()
+            a, adopted = _take_out(self._L, ptr, int(n) * dt.itemsize, dt)
+            if adopted:
+                setattr(res, field, None)   # no longer freed with the rest below
+            return a
 
         out = BatchResult(
-            denoised=arr(res.denoised, res.n_denoised, np.uint8),
-            denoised_offsets=arr(res.denoised_offsets, R + 1, np.uint64),
-            dropped=arr(res.dropped, R, np.uint8),
-            tok_start=arr(res.tok_start, res.n_tokens, np.uint32),
-            tok_len=arr(res.tok_len, res.n_tokens, np.uint32),
-            tok_offsets=arr(res.tok_offsets, R + 1, np.uint64),
-            chunks=arr(res.chunks, res.n_chunks, CHUNK_DTYPE),
-            chunk_offsets=arr(res.chunk_offsets, R + 1, np.uint64),
+            denoised=arr("denoised", res.n_denoised, np.uint8),
+            denoised_offsets=arr("denoised_offsets", R + 1, np.uint64),
+            dropped=arr("dropped", R, np.uint8),
+            tok_start=arr("tok_start", res.n_tokens, np.uint32),
+            tok_len=arr("tok_len", res.n_tokens, np.uint32),
+            tok_offsets=arr("tok_offsets", R + 1, np.uint64),
+            chunks=arr("chunks", res.n_chunks, CHUNK_DTYPE),
+            chunk_offsets=arr("chunk_offsets", R + 1, np.uint64),
             n_records=R, n_denoised=int(res.n_denoised), n_tokens=int(res.n_tokens),
             n_chunks=int(res.n_chunks))
         self._L.trp_result_free(C.byref(res))
@@ -443,9 +480,14 @@ class Context:
         n_chunks = int(res.n_chunks)
         text = offs = None
         if outputs & OUT_CHUNK_TEXT:
-            offs = np.frombuffer(C.string_at(ct.offsets, (n_chunks + 1) * 8), dtype=np.uint64).copy()
-            text = (np.frombuffer(C.string_at(ct.text, int(ct.n_bytes)), dtype=np.uint8).copy() if ct.n_bytes
-                    else np.zeros(0, np.uint8))
+            offs, kept = _take_out(self._L, ct.offsets, (n_chunks + 1) * 8, np.uint64)
+            if kept:
+                ct.offsets = None
+            text = np.zeros(0, np.uint8)
+            if ct.n_bytes:
+                text, kept = _take_out(self._L, ct.text, int(ct.n_bytes), np.uint8)
+                if kept:
+                    ct.text = None
             self._L.trp_chunk_text_free(C.byref(ct))
         out = self._host_result(res, R)
         out.chunk_text_bytes, out.chunk_text_offsets = text, offs

@@ -105,3 +105,48 @@ def test_single_launch_is_used_by_the_device_entry_points(T, both):
         small.set_profiling(False)
         assert ("k_small_batch" in names) == want_small, names
         assert_same(O.batch(data, offs, O.make_config(True, 0.35, True, 1024, (64,), 512)), got, recs, "device %d" % nrec)
+
+
+def test_small_host_batches_come_back_gathered_or_by_copies(T, both):
+    """A small batch in host memory is fetched by the single launch itself and its result arrays are gathered into
+    one page-locked block; results too large for the block (many one-token windows) come back by copy commands.
+    Either way: the oracle's arrays, for every output selection."""
+    small, full = both
+    many = [b"a " * 16000]                                   # 16000 tokens in 32000 bytes
+    prose = textgen.corpus(5, 6)
+    while sum(len(r) for r in prose) > 32000:
+        prose.pop()
+    longer = textgen.corpus(9, 40)                           # host batches take the single launch up to 64 KiB
+    while sum(len(r) for r in longer) > 65000:
+        longer.pop()
+    word = b"alpha 12 beta 345 gamma\n"
+    cases = [(longer, (True, 0.35, True, 64, (8,), 16)),
+             ([word * (65536 // len(word))], (True, 0.35, True, 64, (8,), 16)),
+             ([word * (65536 // len(word) + 2)], (True, 0.35, True, 64, (8,), 16)),   # just beyond: the kernel sequence
+             (prose, (True, 0.35, True, 16, (4,), 8)),          # gathered
+             (prose, (False, 0.35, True, 16, (4,), 8)),         # gathered, the text is the input itself
+             (many, (True, 0.35, True, 2, (1,), 0)),            # ~16000 windows: 640 KiB, still gathered
+             (many, (True, 0.35, True, 2, (1, 0, 1), 0)),       # ~40000 windows: beyond the block
+             (many, (False, 0.35, True, 2, (1, 0, 1), 0))]
+    for recs, cfg in cases:
+        data, offs = O.pack(recs)
+        den = T.DenoiserConfig(cfg[0], cfg[1], cfg[2])
+        st = T.ChunkingStrategy(max_window_tokens=cfg[3], overlap_tokens=list(cfg[4]), summary_fallback_tokens=cfg[5])
+        exp = O.batch(data, offs, O.make_config(*cfg))
+        ref = full.preprocess_batch(data, offs, den, st)
+        assert_same(exp, ref, recs, "kernel sequence %s" % (cfg,))
+        assert_same(exp, small.preprocess_batch(data, offs, den, st), recs, "single launch %s" % (cfg,))
+        for mask in (0, T.OUT_TEXT, T.OUT_TOKENS, T.OUT_CHUNKS, T.OUT_TOKENS | T.OUT_CHUNKS, T.OUT_ALL | T.OUT_CHUNK_TEXT):
+            got = small.preprocess_batch_select(data, offs, den, st, mask)
+            for k in ("denoised_offsets", "tok_offsets", "chunk_offsets", "dropped"):
+                assert np.array_equal(getattr(got, k), getattr(ref, k)), (cfg, mask, k)
+            for flag, names in ((T.OUT_TEXT, ("denoised",)), (T.OUT_TOKENS, ("tok_start", "tok_len")), (T.OUT_CHUNKS, ("chunks",))):
+                for k in names:
+                    if mask & flag:
+                        assert np.array_equal(getattr(got, k), getattr(ref, k)), (cfg, mask, k)
+                    else:
+                        assert len(getattr(got, k)) == 0, (cfg, mask, k)
+            if mask & T.OUT_CHUNK_TEXT:
+                o = got.chunk_text_offsets
+                for c in (0, ref.n_chunks // 2, ref.n_chunks - 1):
+                    assert got.chunk_text_bytes[int(o[c]):int(o[c + 1])].tobytes() == ref.chunk_text(c), (cfg, c)
