@@ -2700,15 +2700,14 @@ __device__ inline u32 below32(u32 j) { return j >= 32 ? ~0u : ((1u << j) - 1u); 
 // PASSTHROUGH: the denoiser is off, the text is the input itself: nothing is copied, k_count_tokens has left the
 // token plane in the plan.
 constexpr int EMIT_WAVES = 4;
-template <bool PASSTHROUGH, int WAVES>
-__device__ __forceinline__ void emit_body(EmitShared* shw, u32 vb, const u8* __restrict__ bytes,
-                                          const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 N,
-                                          u64 nB, u64 nW, const PlanMem& plan, const u64* __restrict__ tile_base,
-                                          u8* __restrict__ denoised, u32* __restrict__ tok_start, u32* __restrict__ tok_len,
-                                          u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
-    EmitShared& sh = shw[threadIdx.x >> 6];
+// Sub-tile t by the calling wavefront (sh: its own LDS).
+template <bool PASSTHROUGH>
+__device__ __forceinline__ void emit_sub(EmitShared& sh, u64 t, const u8* __restrict__ bytes,
+                                         const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 N,
+                                         u64 nB, u64 nW, const PlanMem& plan, const u64* __restrict__ tile_base,
+                                         u8* __restrict__ denoised, u32* __restrict__ tok_start, u32* __restrict__ tok_len,
+                                         u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
     const int tid = threadIdx.x & 63;   // = lane
-    const u64 t = (u64)vb * WAVES + (threadIdx.x >> 6);
     if (t >= nW) return;
     SubRs& srs = *reinterpret_cast<SubRs*>(sh.out);
     EmitIn in;
@@ -2974,6 +2973,15 @@ __device__ __forceinline__ void emit_body(EmitShared* shw, u32 vb, const u8* __r
     }
 }
 template <bool PASSTHROUGH, int WAVES>
+__device__ __forceinline__ void emit_body(EmitShared* shw, u32 vb, const u8* __restrict__ bytes,
+                                          const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R, u64 N,
+                                          u64 nB, u64 nW, const PlanMem& plan, const u64* __restrict__ tile_base,
+                                          u8* __restrict__ denoised, u32* __restrict__ tok_start, u32* __restrict__ tok_len,
+                                          u64* __restrict__ den_off, u64* __restrict__ tok_off, u32 stop_after) {
+    emit_sub<PASSTHROUGH>(shw[threadIdx.x >> 6], (u64)vb * WAVES + (threadIdx.x >> 6), bytes, offsets, rec_lo_w, R, N, nB, nW,
+                          plan, tile_base, denoised, tok_start, tok_len, den_off, tok_off, stop_after);
+}
+template <bool PASSTHROUGH, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8))) void k_emit(const u8* __restrict__ bytes,
                                               const u64* __restrict__ offsets, const u32* __restrict__ rec_lo_w, u64 R,
                                               u64 N, u64 nB, u64 nW, PlanMem plan,
@@ -3028,6 +3036,18 @@ __global__ void k_chunk_emit(const u64* __restrict__ chunk_off, const u64* __res
                              u64 capacity, ChunkDesc* __restrict__ chunks, u64* __restrict__ totals,
                              u64* __restrict__ host_totals) {
     chunk_emit_body(blockIdx.x, gridDim.x, chunk_off, tok_off, R, cfg, capacity, chunks, totals, host_totals);
+}
+
+// The chunk-count scan and the descriptors in one launch, for batches of few records and few descriptors (a
+// dependent launch costs more than this work).
+constexpr u64 CHUNKS_SMALL_MAX_DESC = 65536;
+__global__ __launch_bounds__(NT) void k_chunks_small(GenChunkCounts gen, u64 R, u64* __restrict__ chunk_off, DevCfg cfg,
+                                                      u64 capacity, ChunkDesc* __restrict__ chunks,
+                                                      u64* __restrict__ host_totals) {
+    __shared__ u64 smem[NT / 64];
+    scan_small_body(smem, gen, R, chunk_off);
+    __syncthreads();
+    chunk_emit_body(0u, 1u, chunk_off, gen.tok_off, R, cfg, capacity, chunks, gen.totals, host_totals);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3882,11 +3902,17 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
                                  d_offsets, B.rec_lo_w, R, N, nB, nW, plan, tile_base, B.denoised, B.tok_start, B.tok_len,
                                  den_off, tok_off, c->emit_stop()); }
     }
+    GenChunkCounts gen;
+    gen.tile_base = tile_base; gen.nW = nW; gen.rec_lo_w = B.rec_lo_w; gen.R = R; gen.N = N;
+    gen.passthrough = pass ? 1 : 0; gen.cfg = dc;
+    gen.den_off = den_off; gen.tok_off = tok_off; gen.totals = totals; gen.counts = B.counts; gen.dropped = B.dropped;
+    if (R <= SCAN_SMALL_MAX && B.chunk_cap <= CHUNKS_SMALL_MAX_DESC) {
+        Prof pr(c, "k_chunks_small");
+        hipLaunchKernelGGL(k_chunks_small, dim3(1), dim3(NT), 0, st, gen, R, chunk_off, dc, B.chunk_cap, B.chunks, c->h_totals);
+        HIPCHK(hipGetLastError());
+        return TRP_OK;
+    }
     { Prof pr(c, "scan_chunks");   // with the totals, the trailing offsets and the dropped flags on the way
-      GenChunkCounts gen;
-      gen.tile_base = tile_base; gen.nW = nW; gen.rec_lo_w = B.rec_lo_w; gen.R = R; gen.N = N;
-      gen.passthrough = pass ? 1 : 0; gen.cfg = dc;
-      gen.den_off = den_off; gen.tok_off = tok_off; gen.totals = totals; gen.counts = B.counts; gen.dropped = B.dropped;
       if ((rc = scan_gen(st, B.partial, gen, B.counts, R, chunk_off))) return rc; }
     { Prof pr(c, "k_chunk_emit");
       hipLaunchKernelGGL(k_chunk_emit, dim3((unsigned)std::min<u64>(1024, R / 256 + 1)), dim3(256), 0, st, chunk_off, tok_off, R, dc, B.chunk_cap,

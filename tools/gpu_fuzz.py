@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test: random corpora and random configurations through the GPU library against the oracle.
 
-  python tools/gpu_fuzz.py [--seconds 120] [--seed0 1000]
+  python tools/gpu_fuzz.py [--seconds 120] [--seed0 1000] [--small]
 
 Prints one line per ~20 batches to keep a remote run visibly alive; exits non-zero at the first mismatch
 (the failing seed and configuration are printed)."""
@@ -25,6 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--small", action="store_true",
+                    help="cut every batch to at most 64 KiB: the single-launch path and its gathered results")
     args = ap.parse_args()
     ctx = T.Context(0)
     t_end = time.time() + args.seconds
@@ -52,6 +54,12 @@ def main():
         mwt = rng.choice([1, 2, 7, 64, 1024])
         ov = tuple(rng.choice([0, 1, 3, 64, 2000]) for _ in range(rng.choice([0, 1, 1, 2, 3])))
         sft = rng.choice([0, 1, 16, 512])
+        if args.small:
+            limit = rng.choice([2000, 16000, 32768, 65536])
+            while len(recs) > 1 and sum(len(r) for r in recs) > limit:
+                recs.pop()
+            if sum(len(r) for r in recs) > limit:
+                recs = [recs[0][:limit].decode("utf-8", "ignore").encode()]
         data, offs = O.pack(recs)
         exp = O.batch(data, offs, O.make_config(enabled, ratio, md, mwt, ov, sft), n_threads=8)
         got = ctx.preprocess_batch(data, offs, T.DenoiserConfig(enabled, ratio, md),
