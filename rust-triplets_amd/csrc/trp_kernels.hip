@@ -3060,9 +3060,9 @@ __global__ __launch_bounds__(NT) void k_chunks_small(GenChunkCounts gen, u64 R, 
 // tile seeds cannot be settled from the windows next to the tiles the batch says so in its totals exactly as the
 // full path does, and the host runs it again there.
 constexpr u64 SMALL_MAX_TILES = 2;        // 32 KiB of text: one workgroup takes ~13 us a tile, the kernel sequence ~50 us in all
-// A batch that comes from host memory and goes back there saves the copy commands on both sides as well (they cost
-// more than the kernels at these sizes), which pays up to more tiles.
-constexpr u64 SMALL_HOST_MAX_TILES = 4;   // 64 KiB of text (121 us instead of 180 us for the whole call there)
+// (A batch from host memory has the same limit: beyond two tiles the kernel sequence with its short result arrays
+// packed by one launch, k_pack_small, is as fast - 88 us against 121 us for 64 KiB.)
+constexpr u64 SMALL_HOST_MAX_TILES = SMALL_MAX_TILES;
 constexpr u64 SMALL_MAX_RECORDS = 4096;
 struct SmallArgs {
     const u8* bytes;
@@ -3127,7 +3127,21 @@ __device__ inline void pack_copy(u8* __restrict__ dst, const void* __restrict__ 
     for (u64 i = (q << 4) + threadIdx.x; i < n; i += NT) dst[i] = src[i];
 }
 constexpr u64 SMALL_OUT_CAP = (u64)1 << 20;   // page-locked block for the results of a small host batch
-constexpr u64 SMALL_IN_CAP = SMALL_HOST_MAX_TILES * TILE + 64 + (SMALL_MAX_RECORDS + 1) * sizeof(u64);
+// Several short device arrays into one page-locked host block with one launch: the per-record arrays of a host
+// batch are a few kilobytes each, and a copy command to pageable memory costs 20 us apiece.
+constexpr int PACK_MAX = 12;
+struct PackArgs {
+    const void* src[PACK_MAX];
+    u64 bytes[PACK_MAX];
+    u64 at[PACK_MAX];     // 16-byte aligned offsets into dst
+    int n;
+    u8* dst;
+};
+__global__ __launch_bounds__(NT) void k_pack_small(PackArgs a) {
+    for (int i = blockIdx.x; i < a.n; i += gridDim.x) pack_copy(a.dst + a.at[i], a.src[i], a.bytes[i]);
+}
+constexpr u64 SMALL_IN_CAP = (u64)256 << 10;   // page-locked block for a small host batch, or for the offsets of a larger one
+static_assert(SMALL_IN_CAP >= SMALL_HOST_MAX_TILES * TILE + 64 + (SMALL_MAX_RECORDS + 1) * sizeof(u64), "small batch must fit");
 union SmallShared {
     SeedShared seed;
     PlanShared plan;
@@ -4649,7 +4663,14 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         if ((rc = c->in_bytes.ensure(N + 64))) return rc;
         if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
         if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        if ((R + 1) * sizeof(u64) <= SMALL_IN_CAP) {
+            // a short offsets array through the page-locked block: a copy command that needs no staging
+            if (!c->h_in) HIPCHK(hipHostMalloc((void**)&c->h_in, SMALL_IN_CAP, hipHostMallocDefault));
+            memcpy(c->h_in, offsets, (R + 1) * sizeof(u64));
+            HIPCHK(hipMemcpyAsync(c->in_offsets.p, c->h_in, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        }
         if ((rc = run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, &d))) return rc;
     }
     memset(out, 0, sizeof(*out));
@@ -4657,11 +4678,22 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
     const PackLayout L = pack_layout(R, d.n_denoised, d.n_tokens, d.n_chunks, outputs);
     // one result array: out of the gathered block when the kernel has filled it (`at` = its place there), else by a
     // copy command from the device array
+    // (arrays too short for a page-locked result block, when the single launch has not gathered them already, are
+    // packed into the context's page-locked block by one more launch and copied from there after the synchronise)
+    PackArgs pk;
+    pk.n = 0;
+    void* pk_dst[PACK_MAX];
+    u64 pk_used = 0;
     auto grab = [&](void** dst, const void* src, size_t bytes_, u64 at = ~(u64)0) -> int {
         *dst = host_pool().alloc(bytes_);
         if (!*dst) return fail(TRP_E_ARG, "out of host memory");
         if (bytes_ && gathered && at != ~(u64)0) {
             memcpy(*dst, c->h_out + at, bytes_);
+        } else if (bytes_ && bytes_ < HostPool::PIN_MIN && pk.n < PACK_MAX && pk_used + bytes_ + 16 <= SMALL_OUT_CAP &&
+                   ((uintptr_t)src & 15u) == 0) {
+            pk.src[pk.n] = src; pk.bytes[pk.n] = bytes_; pk.at[pk.n] = pk_used; pk_dst[pk.n] = *dst;
+            pk.n++;
+            pk_used += (bytes_ + 15) & ~(u64)15;
         } else if (bytes_) {
             hipError_t e = hipMemcpyAsync(*dst, src, bytes_, hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) return fail(TRP_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
@@ -4693,10 +4725,19 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         if ((rc = grab((void**)&ctext->offsets, d_cto, (d.n_chunks + 1) * sizeof(u64)))) return fail_free(rc);
         ctext->n_bytes = n_ct;
     }
+    if (pk.n) {
+        if (!c->h_out) {
+            hipError_t e = hipHostMalloc((void**)&c->h_out, SMALL_OUT_CAP, hipHostMallocDefault);
+            if (e != hipSuccess) return fail_free(fail(TRP_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)));
+        }
+        pk.dst = c->h_out;
+        hipLaunchKernelGGL(k_pack_small, dim3((unsigned)pk.n), dim3(NT), 0, c->stream, pk);
+    }
     {
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return fail_free(fail(TRP_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)));
     }
+    for (int i = 0; i < pk.n; i++) memcpy(pk_dst[i], c->h_out + pk.at[i], pk.bytes[i]);
     return TRP_OK;
 }
 

@@ -116,7 +116,7 @@ def test_small_host_batches_come_back_gathered_or_by_copies(T, both):
     prose = textgen.corpus(5, 6)
     while sum(len(r) for r in prose) > 32000:
         prose.pop()
-    longer = textgen.corpus(9, 40)                           # host batches take the single launch up to 64 KiB
+    longer = textgen.corpus(9, 40)                           # beyond the single launch: the kernel sequence, short result arrays packed by one launch
     while sum(len(r) for r in longer) > 65000:
         longer.pop()
     word = b"alpha 12 beta 345 gamma\n"
