@@ -4782,17 +4782,41 @@ static int stage_and_run(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
     HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     return run_device(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, d);
 }
-// Rendered texts (device) -> library-owned host arrays.
+// Rendered texts (device) -> library-owned host arrays.  Short arrays travel through the context's page-locked block
+// by one launch (a copy command to pageable memory costs 20 us), long ones by copy commands into page-locked arrays.
 static int texts_to_host(trp_ctx* c, const uint8_t* d_text, const uint64_t* d_off, uint64_t n, uint64_t nbytes,
                          trp_chunk_text* out) {
     memset(out, 0, sizeof(*out));
     out->offsets = (uint64_t*)host_pool().alloc((n + 1) * sizeof(u64));
     out->text = (uint8_t*)host_pool().alloc(nbytes ? nbytes : 1);
     if (!out->offsets || !out->text) { trp_chunk_text_free(out); return fail(TRP_E_ARG, "out of host memory"); }
-    hipError_t e = hipMemcpyAsync(out->offsets, d_off, (n + 1) * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(out->text, d_text, nbytes, hipMemcpyDeviceToHost, c->stream);
+    PackArgs pk;
+    pk.n = 0;
+    void* pk_dst[2];
+    u64 used = 0;
+    hipError_t e = hipSuccess;
+    auto fetch = [&](void* dst, const void* src, u64 bytes_) {
+        if (!bytes_ || e != hipSuccess) return;
+        if (bytes_ < HostPool::PIN_MIN && used + bytes_ + 16 <= SMALL_OUT_CAP && ((uintptr_t)src & 15u) == 0) {
+            pk.src[pk.n] = src; pk.bytes[pk.n] = bytes_; pk.at[pk.n] = used; pk_dst[pk.n] = dst;
+            pk.n++;
+            used += (bytes_ + 15) & ~(u64)15;
+        } else {
+            e = hipMemcpyAsync(dst, src, bytes_, hipMemcpyDeviceToHost, c->stream);
+        }
+    };
+    fetch(out->offsets, d_off, (n + 1) * sizeof(u64));
+    fetch(out->text, d_text, nbytes);
+    if (e == hipSuccess && pk.n) {
+        if (!c->h_out) e = hipHostMalloc((void**)&c->h_out, SMALL_OUT_CAP, hipHostMallocDefault);
+        if (e == hipSuccess) {
+            pk.dst = c->h_out;
+            hipLaunchKernelGGL(k_pack_small, dim3((unsigned)pk.n), dim3(NT), 0, c->stream, pk);
+        }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { trp_chunk_text_free(out); return fail(TRP_E_HIP, std::string("copy of rendered texts: ") + hipGetErrorString(e)); }
+    for (int i = 0; i < pk.n; i++) memcpy(pk_dst[i], c->h_out + pk.at[i], pk.bytes[i]);
     out->n_bytes = nbytes;
     return TRP_OK;
 }

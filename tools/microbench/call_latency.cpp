@@ -56,8 +56,21 @@ int main() {
             trp_free(out);
         });
         const double chk = median_us([&] { bad |= trp_chunk_section(ctx, (const uint8_t*)text.data(), want, &cfg, &res); });
+        const uint64_t hoff[2] = {0, want};
+        const uint32_t pick[1] = {0}, budget[1] = {40};
+        const double cap = median_us([&] {
+            trp_chunk_text t;
+            bad |= trp_head_tokens_text(ctx, (const uint8_t*)text.data(), hoff, 1, 64, &t);
+            trp_chunk_text_free(&t);
+        });
+        const double body = median_us([&] {
+            trp_chunk_text t;
+            bad |= trp_chunk_bodies(ctx, (const uint8_t*)text.data(), hoff, 1, &cfg, pick, budget, 1, &t);
+            trp_chunk_text_free(&t);
+        });
         std::printf("record of %6zu bytes (%zu tokens): device batch call %.1f us, trp_token_count %.1f us, trp_denoise %.1f us, "
-                    "trp_chunk_section %.1f us%s\n", want, n, dev, cnt, den, chk, bad ? "  (a call FAILED)" : "");
+                    "trp_chunk_section %.1f us, trp_head_tokens_text %.1f us, trp_chunk_bodies %.1f us%s\n", want, n, dev, cnt, den, chk,
+                    cap, body, bad ? "  (a call FAILED)" : "");
         (void)hipFree(d_bytes); (void)hipFree(d_off);
     }
     // batches of 4 KB records in host memory: every array back (trp_preprocess_batch) or descriptors only
