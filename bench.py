@@ -510,6 +510,26 @@ def main():
         del pinned
         L.trp_trim_host_pool()
 
+    # ---- small batches: microseconds per blocking call (a sampler's ingest refresh is kilobytes to megabytes) ----
+    if extras:
+        sb = {}
+        d_all, o_all, _, _ = batches[0][0], batches[0][1], batches[0][2], batches[0][3]
+        for label, want in (("one_record_4KB", 1), ("64KB", 16), ("1MB", 256), ("4MB", 1024)):
+            r = min(want, int(batches[0][2]))
+            n = int(offs[r])
+            for _ in range(30):
+                ctx.preprocess_batch_device(d_all.data_ptr(), o_all.data_ptr(), r, n, den, st)
+            runs = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    ctx.preprocess_batch_device(d_all.data_ptr(), o_all.data_ptr(), r, n, den, st)
+                runs.append((time.perf_counter() - t0) / 100)
+            dt = sorted(runs)[3]
+            sb[label] = {"records": r, "bytes": n, "us_per_call": round(dt * 1e6, 1), "GBps": round(n / dt / 1e9, 2)}
+        out["small_batches"] = {"calls": "blocking trp_preprocess_batch_device from Python, device-resident input, "
+                                         "median of 7 runs of 100 calls", **sb}
+
     # ---- the other single-GPU workloads of BASELINE.json, same context, same timing rules ---------------
     if extras:
         ex = {}

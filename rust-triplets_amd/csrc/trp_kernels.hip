@@ -3920,7 +3920,7 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
     gen.tile_base = tile_base; gen.nW = nW; gen.rec_lo_w = B.rec_lo_w; gen.R = R; gen.N = N;
     gen.passthrough = pass ? 1 : 0; gen.cfg = dc;
     gen.den_off = den_off; gen.tok_off = tok_off; gen.totals = totals; gen.counts = B.counts; gen.dropped = B.dropped;
-    if (R <= SCAN_SMALL_MAX && B.chunk_cap <= CHUNKS_SMALL_MAX_DESC) {
+    if (R <= SCAN_SMALL_MAX && chunk_bound(N, R, dc) <= CHUNKS_SMALL_MAX_DESC) {   // (the bound, not the buffer, which only grows)
         Prof pr(c, "k_chunks_small");
         hipLaunchKernelGGL(k_chunks_small, dim3(1), dim3(NT), 0, st, gen, R, chunk_off, dc, B.chunk_cap, B.chunks, c->h_totals);
         HIPCHK(hipGetLastError());
