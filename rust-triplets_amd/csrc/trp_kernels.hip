@@ -2458,9 +2458,9 @@ struct GenChunkCounts {
 };
 
 constexpr u64 SCAN_SUM_MAX = 8192;
-// Inputs of at most SCAN_SMALL_MAX values (batches of a few megabytes, a few thousand records) are scanned by one
+// Inputs of at most SCAN_SMALL_MAX values (batches of a megabyte or two, a thousand records) are scanned by one
 // workgroup in one launch: at that size a batch is bound by the number of dependent launches, not by bytes.
-constexpr u64 SCAN_SMALL_MAX = 4096;
+constexpr u64 SCAN_SMALL_MAX = 1024;   // (2048 values: 12.7 us in one workgroup against 9.8 us for the two kernels)
 template <class Gen>
 __global__ __launch_bounds__(NT) void k_scan_reduce_gen(Gen gen, u64 n, u64* __restrict__ partial) {
     __shared__ u64 red[NT / 64];
