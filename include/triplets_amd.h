@@ -156,6 +156,27 @@ void trp_chunk_text_free(trp_chunk_text* t);
  * the blocks that are not in use.  No counterpart in the reference (its results are heap Strings). */
 void trp_trim_host_pool(void);
 
+/* A strategy with more than one registered preprocessor (ChunkingStrategy::register_preprocessor,
+ * src/config.rs:105-113): SlidingWindowChunker::materialize folds the section text through them in registration
+ * order and returns no chunks as soon as one returns None (src/chunking/sliding_window.rs:20-34).  The reference
+ * ships one TextPreprocessor, the denoiser, so the fold taken over here is a list of denoisers: `cfg`'s own
+ * first, then `more[0 .. n_more)`; a disabled one returns its text unchanged (denoiser_preprocessor.rs:222-224).
+ * The text of each stage is the input of the next, on the GPU; `out` describes the last stage (denoised = the
+ * fully folded text, dropped = some stage returned None), tokenised and chunked with `cfg`'s chunking fields.
+ * `outputs` / `chunk_text` as in trp_preprocess_batch_select (TRP_OUT_ALL and NULL: every array, no chunk text).
+ * Otherwise as trp_preprocess_batch / trp_preprocess_batch_device. */
+typedef struct {
+    uint8_t denoise_enabled;
+    uint8_t strip_markdown;
+    float max_digit_ratio;
+} trp_denoiser;
+int trp_preprocess_batch_fold(trp_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                              const trp_config* cfg, const trp_denoiser* more, uint32_t n_more, uint32_t outputs,
+                              trp_result* out, trp_chunk_text* chunk_text);
+int trp_preprocess_batch_device_fold(trp_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                                     uint64_t n_records, uint64_t n_bytes, const trp_config* cfg,
+                                     const trp_denoiser* more, uint32_t n_more, trp_result* out);
+
 /* Same path with the batch already resident in GPU memory (16-byte aligned `d_bytes`, device
  * `d_offsets`).  The result arrays are device pointers into buffers owned by the context; they stay
  * valid until the next call on this context.  The call returns after the kernels have completed

@@ -3497,6 +3497,7 @@ struct trp_ctx {
     DevBuf rec_lo, rec_lo_w, SA, seedJ, seedS, plan, g3list, tile_bytes, tile_toks, tile_flags, packed, tile_base, partial;
     DevBuf denoised, den_off, dropped, tok_start, tok_len, tok_off, counts, chunk_off, chunks, totals;
     DevBuf in_bytes, in_offsets;        // staging of the host-memory entry point
+    DevBuf fold_bytes, fold_offsets;    // text between two stages of a preprocessor fold (run_device_fold)
     DevBuf text, text_off, text_len;    // chunk text
     DevBuf far_list;                    // tiles whose carries need a long walk (k_tile_carry)
     DevBuf heads;                       // head-of-record / chunk-body descriptors (trp_head_tokens_text_device, trp_chunk_bodies_device)
@@ -3728,7 +3729,7 @@ void trp_destroy(trp_ctx* c) {
                       &c->g3list, &c->tile_bytes, &c->tile_toks, &c->tile_flags, &c->packed,
                       &c->tile_base, &c->partial, &c->denoised, &c->den_off, &c->dropped, &c->tok_start,
                       &c->tok_len, &c->tok_off, &c->counts, &c->chunk_off, &c->chunks, &c->totals,
-                      &c->in_bytes, &c->in_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list, &c->sel};
+                      &c->in_bytes, &c->in_offsets, &c->fold_bytes, &c->fold_offsets, &c->text, &c->text_off, &c->text_len, &c->heads, &c->far_list, &c->sel};
     for (DevBuf* b : bufs) b->release();
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -4206,6 +4207,51 @@ static int run_device(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     return collect_device(c, out);
 }
 
+// The preprocessor fold of a strategy with several denoisers (sliding_window.rs:20-34): the stages that do
+// something run one after the other as whole batches, the text of one being the input of the next.  A record a
+// stage returns None for has no text; the next stage returns None for an empty text as well, so the flags of the
+// last stage say "some stage returned None" - as long as every stage that runs is an enabled one, which is why the
+// disabled ones (identity, denoiser_preprocessor.rs:222-224) are left out rather than run as pass-through stages.
+static int run_device_fold(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
+                           const DevCfg& dc, const trp_denoiser* more, uint32_t n_more, trp_result* out) {
+    if (!c || !out) return fail(TRP_E_ARG, "ctx/out is null");
+    if (n_more && !more) return fail(TRP_E_ARG, "more is null");
+    if (dc.normalize) return fail(TRP_E_ARG, "the fold takes denoisers only");
+    std::vector<DevCfg> stages;
+    if (dc.denoise_enabled) stages.push_back(dc);
+    for (uint32_t i = 0; i < n_more; i++) {
+        if (!more[i].denoise_enabled) continue;
+        DevCfg x = dc;
+        x.denoise_enabled = 1;
+        x.strip_markdown = more[i].strip_markdown ? 1 : 0;
+        x.max_digit_ratio = more[i].max_digit_ratio;
+        stages.push_back(x);
+    }
+    if (stages.empty()) {
+        DevCfg x = dc;
+        x.denoise_enabled = 0;
+        return run_device(c, d_bytes, d_offsets, R, N, x, out);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const uint8_t* in_b = d_bytes;
+    const uint64_t* in_o = d_offsets;
+    uint64_t n = N;
+    for (size_t k = 0; k < stages.size(); k++) {
+        int rc = run_device(c, in_b, in_o, R, n, stages[k], out);
+        if (rc || k + 1 == stages.size()) return rc;
+        // (the context's result arrays are overwritten by the next stage: its input goes into arrays of its own)
+        if ((rc = c->fold_bytes.ensure(out->n_denoised + 64))) return rc;
+        if ((rc = c->fold_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
+        if (out->n_denoised)
+            HIPCHK(hipMemcpyAsync(c->fold_bytes.p, out->denoised, out->n_denoised, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->fold_offsets.p, out->denoised_offsets, (R + 1) * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        in_b = c->fold_bytes.as<u8>();
+        in_o = c->fold_offsets.as<u64>();
+        n = out->n_denoised;
+    }
+    return TRP_OK;
+}
+
 // Text of `C` descriptors over the last device batch: lengths, scan, emit.  chunk_off == nullptr for head
 // descriptors.
 static int render_text(trp_ctx* c, const ChunkDesc* chunks, u64 C, const u64* chunk_off, uint8_t** d_text,
@@ -4640,7 +4686,8 @@ static int run_small_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offs
 }
 
 static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const DevCfg& dc,
-                    trp_result* out, uint32_t outputs = TRP_OUT_ALL, trp_chunk_text* ctext = nullptr) {
+                    trp_result* out, uint32_t outputs = TRP_OUT_ALL, trp_chunk_text* ctext = nullptr,
+                    const trp_denoiser* more = nullptr, uint32_t n_more = 0) {
     if (!c || !out || !offsets) return fail(TRP_E_ARG, "null argument");
     if ((outputs & TRP_OUT_CHUNK_TEXT) && !ctext) return fail(TRP_E_ARG, "chunk text requested without a place for it");
     if (ctext) memset(ctext, 0, sizeof(*ctext));
@@ -4652,12 +4699,18 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
     for (u64 r = 0; r < R; r++)
         if (offsets[r + 1] < offsets[r]) return fail(TRP_E_ARG, "offsets must be non-decreasing");
     const char* no_pipe = getenv("TRP_NO_PIPELINE");
-    if (N >= PIPE_MIN_BYTES && R >= 2 && dc.denoise_enabled && !(no_pipe && atoi(no_pipe)))
+    if (N >= PIPE_MIN_BYTES && R >= 2 && dc.denoise_enabled && !(no_pipe && atoi(no_pipe)) && n_more == 0)
         return run_host_pipelined(c, bytes, offsets, R, dc, outputs, out, ctext);
     int rc;
     trp_result d;
     bool gathered = false;
-    if (small_host_ok(c, N, R)) {
+    if (n_more) {   // a fold of several denoisers: the stages run on the device one after the other
+        if ((rc = c->in_bytes.ensure(N + 64))) return rc;
+        if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
+        if (N) HIPCHK(hipMemcpyAsync(c->in_bytes.p, bytes, N, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->in_offsets.p, offsets, (R + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        if ((rc = run_device_fold(c, c->in_bytes.as<u8>(), c->in_offsets.as<u64>(), R, N, dc, more, n_more, &d))) return rc;
+    } else if (small_host_ok(c, N, R)) {
         if ((rc = run_small_host(c, bytes, offsets, R, N, dc, true, outputs, &d, &gathered))) return rc;
     } else {
         if ((rc = c->in_bytes.ensure(N + 64))) return rc;
@@ -4756,6 +4809,25 @@ int trp_preprocess_batch_select(trp_ctx* c, const uint8_t* bytes, const uint64_t
     if (rc) return rc;
     if (outputs & ~(TRP_OUT_ALL | TRP_OUT_CHUNK_TEXT)) return fail(TRP_E_ARG, "unknown output selector");
     return run_host(c, bytes, offsets, R, dc, out, outputs, chunk_text);
+}
+
+int trp_preprocess_batch_fold(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t R, const trp_config* cfg,
+                              const trp_denoiser* more, uint32_t n_more, uint32_t outputs, trp_result* out,
+                              trp_chunk_text* chunk_text) {
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    if (n_more && !more) return fail(TRP_E_ARG, "more is null");
+    if (outputs & ~(TRP_OUT_ALL | TRP_OUT_CHUNK_TEXT)) return fail(TRP_E_ARG, "unknown output selector");
+    return run_host(c, bytes, offsets, R, dc, out, outputs, chunk_text, more, n_more);
+}
+
+int trp_preprocess_batch_device_fold(trp_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t R, uint64_t N,
+                                     const trp_config* cfg, const trp_denoiser* more, uint32_t n_more, trp_result* out) {
+    DevCfg dc;
+    int rc = make_devcfg(cfg, &dc);
+    if (rc) return rc;
+    return run_device_fold(c, d_bytes, d_offsets, R, N, dc, more, n_more, out);
 }
 
 // ---- the steps after the path over host memory ------------------------------------------------------------

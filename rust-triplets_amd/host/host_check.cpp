@@ -219,6 +219,29 @@ int main() {
         // a lookup that follows the miss is a hit
         const size_t nb = cache.gpu_batches();
         EXPECT(cache.materialize(st, "r2", 4, "x y z").size() == 1 && cache.gpu_batches() == nb);
+        {
+            // Two registered denoisers (config.rs:105-113): the text is folded through them in order and the
+            // section is gone as soon as one returns None (sliding_window.rs:20-34).  The first keeps the line
+            // "ab 12 34" (two of six letters and digits are letters: ratio 0.67 is not above 0.9) and the second, with
+            // the default ratio, strips its digit tokens; a section the first one empties stays dropped; a disabled
+            // second one changes nothing.
+            ChunkingStrategy two;
+            two.register_denoiser({.enabled = true, .max_digit_ratio = 0.9f});
+            two.register_denoiser({.enabled = true});
+            BatchPreprocessor bp(ctx);
+            auto r2 = bp.run({"words stay\nab 12 34", "123 456\n---", "plain"}, two);
+            EXPECT(r2.text(0) == "words stay\nab" && !r2.dropped(0));
+            EXPECT(r2.dropped(1) && r2.chunks(1, "x", 1).empty());
+            EXPECT(r2.text(2) == "plain");
+            ChunkingStrategy one;
+            one.register_denoiser({.enabled = true, .max_digit_ratio = 0.9f});
+            one.register_denoiser({.enabled = false});
+            auto r1 = bp.run({"words stay\nab 12 34"}, one);
+            EXPECT(r1.text(0) == "words stay\nab 12 34");
+            ChunkCache folded(ctx);
+            auto fc = folded.materialize(two, "f", 0, "words stay\nab 12 34");
+            EXPECT(fc.size() == 1 && fc[0].text == "words stay\nab" && folded.token_count("f", 0).value() == 5);
+        }
         std::puts("host_check: ok");
         return 0;
     } catch (const Error& e) {

@@ -53,9 +53,14 @@ struct ChunkingStrategy {
     float summary_fallback_weight = 0.35f;
     size_t summary_fallback_tokens = 512;
     float chunk_weight_floor = 0.1f;
-    // The one preprocessor the GPU path implements; set by register_denoiser.
+    // The preprocessors of the strategy, in registration order (ChunkingStrategy::register_preprocessor,
+    // src/config.rs:105-113).  The GPU path implements the reference's one TextPreprocessor, the denoiser:
+    // `denoiser` is the first one registered, `more_denoisers` those after it.
     std::optional<DenoiserConfig> denoiser;
-    void register_denoiser(const DenoiserConfig& c) { denoiser = c; }
+    std::vector<DenoiserConfig> more_denoisers;
+    void register_denoiser(const DenoiserConfig& c) {
+        if (!denoiser) denoiser = c; else more_denoisers.push_back(c);
+    }
 };
 
 struct ChunkView {
@@ -103,6 +108,11 @@ inline trp_config make_config(const ChunkingStrategy& st, const std::vector<uint
     c.summary_fallback_tokens =
         st.summary_fallback_tokens > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)st.summary_fallback_tokens;
     return c;
+}
+inline std::vector<trp_denoiser> more_of(const ChunkingStrategy& st) {
+    std::vector<trp_denoiser> v;
+    for (const DenoiserConfig& d : st.more_denoisers) v.push_back(trp_denoiser{d.enabled, d.strip_markdown, d.max_digit_ratio});
+    return v;
 }
 }  // namespace detail
 
@@ -201,7 +211,9 @@ public:
         trp_config c = detail::make_config(st, ov);
         BatchResult out;
         out.weight_ = st.summary_fallback_weight;
-        check(trp_preprocess_batch_select(ctx_.raw(), bytes.data(), offs.data(), sections.size(), &c, outputs, &out.r_, nullptr));
+        auto more = detail::more_of(st);
+        check(trp_preprocess_batch_fold(ctx_.raw(), bytes.data(), offs.data(), sections.size(), &c, more.data(),
+                                        (uint32_t)more.size(), outputs, &out.r_, nullptr));
         return out;
     }
     BatchResult run_packed(const uint8_t* bytes, const uint64_t* offsets, size_t n, const ChunkingStrategy& st) {
@@ -209,7 +221,9 @@ public:
         trp_config c = detail::make_config(st, ov);
         BatchResult out;
         out.weight_ = st.summary_fallback_weight;
-        check(trp_preprocess_batch(ctx_.raw(), bytes, offsets, n, &c, &out.r_));
+        auto more = detail::more_of(st);
+        check(trp_preprocess_batch_fold(ctx_.raw(), bytes, offsets, n, &c, more.data(), (uint32_t)more.size(), TRP_OUT_ALL,
+                                        &out.r_, nullptr));
         return out;
     }
 
@@ -271,6 +285,8 @@ public:
     }
     ShardedResult run_packed(const uint8_t* bytes, const uint64_t* offsets, size_t n, const ChunkingStrategy& st) {
         const size_t G = ctxs_.size();
+        for (const DenoiserConfig& d : st.more_denoisers)
+            if (d.enabled) throw Error(TRP_E_ARG, "triplets_amd: a strategy with several denoisers runs on BatchPreprocessor");
         ShardedResult out;
         out.first_.assign(G + 1, n);
         out.first_[0] = 0;
@@ -664,6 +680,12 @@ public:
             mix(r);
             mix(st.denoiser->strip_markdown);
         }
+        for (const DenoiserConfig& d : st.more_denoisers) {   // (a disabled one changes nothing)
+            if (!d.enabled) continue;
+            std::memcpy(&r, &d.max_digit_ratio, 4);
+            mix(0x100u | (d.strip_markdown ? 1u : 0u));
+            mix(r);
+        }
         return h;
     }
     // 64-bit hash of a section text (eight bytes per step, FNV-style multiply, final avalanche).
@@ -757,9 +779,12 @@ private:
         BatchResult r = bp.run(texts, st);
         batches_++;
         std::vector<size_t> raw(sections.size());
-        if (st.denoiser && st.denoiser->enabled) {
+        bool denoising = st.denoiser && st.denoiser->enabled;
+        for (const DenoiserConfig& d : st.more_denoisers) denoising = denoising || d.enabled;
+        if (denoising) {
             ChunkingStrategy plain = st;
             plain.denoiser.reset();
+            plain.more_denoisers.clear();
             BatchResult t = bp.run_select(texts, plain, 0);   // per-record arrays only: the token offsets
             batches_++;
             for (size_t i = 0; i < sections.size(); i++) raw[i] = t.token_count(i);

@@ -63,6 +63,15 @@ pub struct trp_chunk_text {
     pub n_bytes: u64,
 }
 
+/// One more DenoiserPreprocessor of a strategy's fold (see trp_preprocess_batch_fold).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct trp_denoiser {
+    pub denoise_enabled: u8,
+    pub strip_markdown: u8,
+    pub max_digit_ratio: f32,
+}
+
 extern "C" {
     pub fn trp_create(device: c_int, out: *mut *mut trp_ctx) -> c_int;
     pub fn trp_device_count() -> c_int;
@@ -83,6 +92,21 @@ extern "C" {
         offsets: *const u64,
         n_records: u64,
         cfg: *const trp_config,
+        outputs: u32,
+        out: *mut trp_result,
+        chunk_text: *mut trp_chunk_text,
+    ) -> c_int;
+    /// The same for a strategy with several registered denoisers: `cfg`'s own first, then `more` in order
+    /// (ChunkingStrategy::register_preprocessor, src/config.rs:105-113; the fold of
+    /// src/chunking/sliding_window.rs:20-34).
+    pub fn trp_preprocess_batch_fold(
+        ctx: *mut trp_ctx,
+        bytes: *const u8,
+        offsets: *const u64,
+        n_records: u64,
+        cfg: *const trp_config,
+        more: *const trp_denoiser,
+        n_more: u32,
         outputs: u32,
         out: *mut trp_result,
         chunk_text: *mut trp_chunk_text,

@@ -92,6 +92,7 @@ impl Batch {
         ctx: &Context,
         texts: &[&str],
         denoiser: Option<&DenoiserConfig>,
+        more: &[DenoiserConfig],
         st: &ChunkingStrategy,
         outputs: u32,
     ) -> Result<Batch, String> {
@@ -104,15 +105,18 @@ impl Batch {
         }
         let overlaps: Vec<u32> = st.overlap_tokens.iter().map(|&o| o.min(u32::MAX as usize) as u32).collect();
         let cfg = Self::config(denoiser, st, &overlaps);
+        let more = Self::more(more);
         let mut raw: ffi::trp_result = unsafe { std::mem::zeroed() };
         let guard = ctx.raw.lock().unwrap();
         let rc = unsafe {
-            ffi::trp_preprocess_batch_select(
+            ffi::trp_preprocess_batch_fold(
                 *guard,
                 bytes.as_ptr(),
                 offsets.as_ptr(),
                 texts.len() as u64,
                 &cfg,
+                more.as_ptr(),
+                more.len() as u32,
                 outputs,
                 &mut raw,
                 std::ptr::null_mut::<ffi::trp_chunk_text>(),
@@ -121,10 +125,21 @@ impl Batch {
         drop(guard);
         if rc != ffi::TRP_OK {
             let e = last_error();
-            log_error("trp_preprocess_batch_select");
+            log_error("trp_preprocess_batch_fold");
             return Err(e);
         }
         Ok(Batch { raw })
+    }
+
+    /// The denoisers registered after the first one, as the C ABI takes them.
+    fn more(more: &[DenoiserConfig]) -> Vec<ffi::trp_denoiser> {
+        more.iter()
+            .map(|d| ffi::trp_denoiser {
+                denoise_enabled: d.enabled as u8,
+                strip_markdown: d.strip_markdown as u8,
+                max_digit_ratio: d.max_digit_ratio,
+            })
+            .collect()
     }
 
     fn config(denoiser: Option<&DenoiserConfig>, st: &ChunkingStrategy, overlaps: &[u32]) -> ffi::trp_config {
@@ -145,6 +160,7 @@ impl Batch {
         ctx: &Context,
         texts: &[&str],
         denoiser: Option<&DenoiserConfig>,
+        more: &[DenoiserConfig],
         st: &ChunkingStrategy,
     ) -> Result<(Batch, ChunkText), String> {
         let (bytes, offsets) = pack(texts);
@@ -152,14 +168,17 @@ impl Batch {
         let cfg = Self::config(denoiser, st, &overlaps);
         let mut raw: ffi::trp_result = unsafe { std::mem::zeroed() };
         let mut ct: ffi::trp_chunk_text = unsafe { std::mem::zeroed() };
+        let more = Self::more(more);
         let guard = ctx.raw.lock().unwrap_or_else(|p| p.into_inner());
         let rc = unsafe {
-            ffi::trp_preprocess_batch_select(
+            ffi::trp_preprocess_batch_fold(
                 *guard,
                 bytes.as_ptr(),
                 offsets.as_ptr(),
                 texts.len() as u64,
                 &cfg,
+                more.as_ptr(),
+                more.len() as u32,
                 ffi::TRP_OUT_CHUNKS | ffi::TRP_OUT_CHUNK_TEXT,
                 &mut raw,
                 &mut ct,
@@ -168,7 +187,7 @@ impl Batch {
         drop(guard);
         if rc != ffi::TRP_OK {
             let e = last_error();
-            log_error("trp_preprocess_batch_select");
+            log_error("trp_preprocess_batch_fold");
             return Err(e);
         }
         Ok((Batch { raw }, ChunkText { raw: ct }))
@@ -254,7 +273,7 @@ type Proto = (ChunkView, String, usize);
 type Key = (u64, String, usize);
 
 /// FNV-1a over everything of the strategy and the denoiser settings that changes the result.
-fn strategy_fingerprint(st: &ChunkingStrategy, den: Option<&DenoiserConfig>) -> u64 {
+fn strategy_fingerprint(st: &ChunkingStrategy, den: Option<&DenoiserConfig>, more: &[DenoiserConfig]) -> u64 {
     let mut h: u64 = 0xcbf2_9ce4_8422_2325;
     let mut mix = |v: u64| {
         for b in v.to_le_bytes() {
@@ -274,6 +293,10 @@ fn strategy_fingerprint(st: &ChunkingStrategy, den: Option<&DenoiserConfig>) -> 
     if let Some(d) = den.filter(|d| d.enabled) {
         mix(d.max_digit_ratio.to_bits() as u64);
         mix(d.strip_markdown as u64);
+    }
+    for d in more.iter().filter(|d| d.enabled) {
+        mix(0x100 | d.strip_markdown as u64);
+        mix(d.max_digit_ratio.to_bits() as u64);
     }
     h
 }
@@ -332,12 +355,14 @@ struct Miss {
 /// `budget_bytes` of chunk text and drops the entries inserted first beyond that; `invalidate` drops a record.
 ///
 /// A strategy that carries registered preprocessors (`strategy.preprocessors()` non-empty) cannot be
-/// served: the GPU path implements the denoiser only, and running arbitrary host preprocessors would
-/// need the reference's CPU chunker.  Such a call records an error, logs it and returns no chunks;
+/// served: the trait objects are opaque, the GPU path implements the denoiser only (one, or a fold of several:
+/// `with_denoisers`), and running arbitrary host preprocessors would need the reference's CPU chunker.  Such a call records an error, logs it and returns no chunks;
 /// give such samplers the reference's own `SlidingWindowChunker`.
 pub struct GpuSlidingWindowChunker {
     ctx: Context,
     denoiser: Option<DenoiserConfig>,
+    /// denoisers registered after the first one: the text is folded through all of them in order
+    more: Vec<DenoiserConfig>,
     table: RwLock<Table>,
     budget_bytes: usize,
     queue: Mutex<Vec<Arc<Miss>>>,
@@ -352,10 +377,23 @@ impl GpuSlidingWindowChunker {
         Self::with_budget(device, denoiser, DEFAULT_BUDGET_BYTES)
     }
 
+    /// A chunker for a strategy that would register several `DenoiserPreprocessor`s
+    /// (`ChunkingStrategy::register_preprocessor`, src/config.rs:105-113): the section text is folded through
+    /// them in this order on the GPU, and a section is dropped as soon as one returns `None`
+    /// (src/chunking/sliding_window.rs:20-34).
+    pub fn with_denoisers(device: i32, denoisers: Vec<DenoiserConfig>, budget_bytes: usize) -> Result<Self, String> {
+        let mut it = denoisers.into_iter();
+        let first = it.next();
+        let mut me = Self::with_budget(device, first, budget_bytes)?;
+        me.more = it.collect();
+        Ok(me)
+    }
+
     pub fn with_budget(device: i32, denoiser: Option<DenoiserConfig>, budget_bytes: usize) -> Result<Self, String> {
         Ok(Self {
             ctx: Context::new(device)?,
             denoiser,
+            more: Vec::new(),
             table: RwLock::new(Table::default()),
             budget_bytes,
             queue: Mutex::new(Vec::new()),
@@ -418,15 +456,15 @@ impl GpuSlidingWindowChunker {
         keys: &[(String, usize)],
         texts: &[&str],
     ) -> Result<Vec<Arc<Vec<Proto>>>, String> {
-        let (batch, chunk_text) = Batch::run_with_chunk_text(&self.ctx, texts, self.denoiser.as_ref(), strategy)?;
-        let denoising = self.denoiser.as_ref().map_or(false, |d| d.enabled);
+        let (batch, chunk_text) = Batch::run_with_chunk_text(&self.ctx, texts, self.denoiser.as_ref(), &self.more, strategy)?;
+        let denoising = self.denoiser.as_ref().map_or(false, |d| d.enabled) || self.more.iter().any(|d| d.enabled);
         let raw: Vec<usize> = if denoising {
-            let plain = Batch::run(&self.ctx, texts, None, strategy, 0)?;
+            let plain = Batch::run(&self.ctx, texts, None, &[], strategy, 0)?;
             (0..texts.len()).map(|r| plain.token_count(r)).collect()
         } else {
             (0..texts.len()).map(|r| batch.token_count(r)).collect()
         };
-        let fp = strategy_fingerprint(strategy, self.denoiser.as_ref());
+        let fp = strategy_fingerprint(strategy, self.denoiser.as_ref(), &self.more);
         let protos: Vec<Arc<Vec<Proto>>> = (0..texts.len())
             .map(|r| Arc::new(batch.chunks_with_text(r, &chunk_text, strategy.summary_fallback_weight)))
             .collect();
@@ -529,7 +567,7 @@ impl ChunkingAlgorithm for GpuSlidingWindowChunker {
             eprintln!("triplets-amd: strategy with registered preprocessors given to the GPU chunker; no chunks");
             return Vec::new();
         }
-        let key: Key = (strategy_fingerprint(strategy, self.denoiser.as_ref()), record.id.to_string(), section_idx);
+        let key: Key = (strategy_fingerprint(strategy, self.denoiser.as_ref(), &self.more), record.id.to_string(), section_idx);
         let th = text_hash(&section.text);
         let hit = {
             let t = self.table.read().unwrap_or_else(|p| p.into_inner());
@@ -747,7 +785,7 @@ pub fn preprocess_sharded(
             .map(|k| {
                 let (ctx, part) = (&ctxs[k], &texts[cuts[k]..cuts[k + 1]]);
                 scope.spawn(move || -> Result<Vec<Vec<Proto>>, String> {
-                    let (batch, chunk_text) = Batch::run_with_chunk_text(ctx, part, denoiser, strategy)?;
+                    let (batch, chunk_text) = Batch::run_with_chunk_text(ctx, part, denoiser, &[], strategy)?;
                     Ok((0..part.len())
                         .map(|r| batch.chunks_with_text(r, &chunk_text, strategy.summary_fallback_weight))
                         .collect())

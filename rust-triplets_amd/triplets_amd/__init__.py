@@ -83,6 +83,10 @@ class _Result(C.Structure):
                 ("n_chunks", C.c_uint64)]
 
 
+class _Denoiser(C.Structure):
+    _fields_ = [("denoise_enabled", C.c_uint8), ("strip_markdown", C.c_uint8), ("max_digit_ratio", C.c_float)]
+
+
 class _ChunkText(C.Structure):
     _fields_ = [("text", C.c_void_p), ("offsets", C.c_void_p), ("n_bytes", C.c_uint64)]
 
@@ -112,7 +116,8 @@ EXPORTS = ["trp_create", "trp_destroy", "trp_last_error", "trp_stream", "trp_pre
            "trp_chunk_section", "trp_free", "trp_set_profiling", "trp_get_profile", "trp_trim_host_pool", "trp_normalize_batch",
            "trp_normalize_batch_device", "trp_normalize_inline_whitespace", "trp_head_tokens_text_device",
            "trp_submit_batch_device", "trp_wait_batch", "trp_create_on_stream", "trp_wait_event", "trp_chunk_bodies_device", "trp_bm25_texts_device", "trp_preprocess_batch_select",
-           "trp_chunk_text_free", "trp_token_bound", "trp_preprocess_batch_device_noalloc", "trp_device_count", "trp_bm25_texts", "trp_chunk_bodies", "trp_head_tokens_text"]
+           "trp_chunk_text_free", "trp_token_bound", "trp_preprocess_batch_device_noalloc", "trp_device_count", "trp_bm25_texts", "trp_chunk_bodies", "trp_head_tokens_text",
+           "trp_preprocess_batch_fold", "trp_preprocess_batch_device_fold"]
 
 _lib = None
 
@@ -156,6 +161,12 @@ def load_library():
     L.trp_preprocess_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.POINTER(_Config), C.POINTER(_Result)]
     L.trp_result_free.argtypes = [C.POINTER(_Result)]
+    L.trp_preprocess_batch_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Config),
+                                            C.POINTER(_Denoiser), C.c_uint32, C.c_uint32, C.POINTER(_Result),
+                                            C.POINTER(_ChunkText)]
+    L.trp_preprocess_batch_device_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                                   C.POINTER(_Config), C.POINTER(_Denoiser), C.c_uint32,
+                                                   C.POINTER(_Result)]
     L.trp_preprocess_batch_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(_Config),
                                               C.c_uint32, C.POINTER(_Result), C.POINTER(_ChunkText)]
     L.trp_chunk_text_free.argtypes = [C.POINTER(_ChunkText)]
@@ -487,6 +498,39 @@ class Context:
         _check(self._L.trp_preprocess_batch(self._h, data.ctypes.data if data.size else None,
                                             offsets.ctypes.data, R, C.byref(cfg), C.byref(res)))
         return self._host_result(res, R)
+
+    @staticmethod
+    def _fold_args(denoisers: Sequence[DenoiserConfig]):
+        """(first denoiser, ctypes array of the others, their number) of a preprocessor fold."""
+        denoisers = list(denoisers)
+        first = denoisers[0] if denoisers else DenoiserConfig(False, 0.35, True)
+        rest = denoisers[1:]
+        arr = (_Denoiser * max(1, len(rest)))(*[_Denoiser(int(d.enabled), int(d.strip_markdown), float(d.max_digit_ratio))
+                                                for d in rest])
+        return first, arr, len(rest)
+
+    def preprocess_batch_fold(self, data: np.ndarray, offsets: np.ndarray, denoisers: Sequence[DenoiserConfig],
+                              strategy: ChunkingStrategy) -> BatchResult:
+        """preprocess_batch for a strategy with several registered denoisers: the section texts are folded through
+        them in order (src/chunking/sliding_window.rs:20-34), a section is dropped as soon as one returns None."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        R = len(offsets) - 1
+        first, arr, n = self._fold_args(denoisers)
+        cfg = _make_cfg(first, strategy)
+        res = _Result()
+        _check(self._L.trp_preprocess_batch_fold(self._h, data.ctypes.data if data.size else None, offsets.ctypes.data, R,
+                                                 C.byref(cfg), arr, n, OUT_ALL, C.byref(res), None))
+        return self._host_result(res, R)
+
+    def preprocess_batch_device_fold(self, d_bytes: int, d_offsets: int, n_records: int, n_bytes: int,
+                                     denoisers: Sequence[DenoiserConfig], strategy: ChunkingStrategy) -> "DeviceResult":
+        first, arr, n = self._fold_args(denoisers)
+        cfg = _make_cfg(first, strategy)
+        res = _Result()
+        _check(self._L.trp_preprocess_batch_device_fold(self._h, d_bytes, d_offsets, n_records, n_bytes, C.byref(cfg),
+                                                        arr, n, C.byref(res)))
+        return DeviceResult(self, res)
 
     def preprocess_batch_select(self, data: np.ndarray, offsets: np.ndarray, denoiser: DenoiserConfig,
                                 strategy: ChunkingStrategy, outputs: int) -> BatchResult:
