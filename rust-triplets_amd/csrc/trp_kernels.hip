@@ -3126,7 +3126,8 @@ __device__ inline void pack_copy(u8* __restrict__ dst, const void* __restrict__ 
     for (u64 i = threadIdx.x; i < q; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
     for (u64 i = (q << 4) + threadIdx.x; i < n; i += NT) dst[i] = src[i];
 }
-constexpr u64 SMALL_OUT_CAP = (u64)1 << 20;   // page-locked block for the results of a small host batch
+constexpr u64 SMALL_OUT_CAP = (u64)1 << 20;   // page-locked block for the results of a small host batch ...
+constexpr u64 H_OUT_BYTES = 2 * SMALL_OUT_CAP;  // ... and as much again behind it for rendered texts (k_render_text_small)
 // Several short device arrays into one page-locked host block with one launch: the per-record arrays of a host
 // batch are a few kilobytes each, and a copy command to pageable memory costs 20 us apiece.
 constexpr int PACK_MAX = 12;
@@ -3258,14 +3259,11 @@ __global__ void k_head_desc(const u64* __restrict__ tok_off, u64 R, u32 k, Chunk
     out[r] = d;
 }
 
-// one wave per chunk
-__global__ __launch_bounds__(NT) void k_chunk_text_len(const ChunkDesc* __restrict__ chunks, u64 C,
-                                                        const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off,
-                                                        const u64* __restrict__ den_off, const u32* __restrict__ tok_len,
-                                                        u64* __restrict__ lens) {
+// one wave per chunk: chunk i by the calling wavefront
+__device__ inline void chunk_text_len_body(u64 i, const ChunkDesc* __restrict__ chunks, const u64* __restrict__ chunk_off,
+                                           const u64* __restrict__ tok_off, const u64* __restrict__ den_off,
+                                           const u32* __restrict__ tok_len, u64* __restrict__ lens) {
     const int lane = threadIdx.x & 63;
-    u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= C) return;
     ChunkDesc c = chunks[i];
     u64 r = c.record;
     if (chunk_is_whole_record(c, chunk_off, tok_off)) {
@@ -3279,15 +3277,20 @@ __global__ __launch_bounds__(NT) void k_chunk_text_len(const ChunkDesc* __restri
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) lens[i] = c.tok_end > c.tok_begin ? s + (c.tok_end - c.tok_begin - 1) : 0;
 }
+__global__ __launch_bounds__(NT) void k_chunk_text_len(const ChunkDesc* __restrict__ chunks, u64 C,
+                                                        const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off,
+                                                        const u64* __restrict__ den_off, const u32* __restrict__ tok_len,
+                                                        u64* __restrict__ lens) {
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i < C) chunk_text_len_body(i, chunks, chunk_off, tok_off, den_off, tok_len, lens);
+}
 
-__global__ __launch_bounds__(NT) void k_chunk_text_emit(const ChunkDesc* __restrict__ chunks, u64 C,
-                                                         const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off,
-                                                         const u64* __restrict__ den_off, const u32* __restrict__ tok_start,
-                                                         const u32* __restrict__ tok_len, const u8* __restrict__ denoised,
-                                                         const u64* __restrict__ text_off, u8* __restrict__ text) {
+__device__ inline void chunk_text_emit_body(u64 i, const ChunkDesc* __restrict__ chunks, const u64* __restrict__ chunk_off,
+                                            const u64* __restrict__ tok_off, const u64* __restrict__ den_off,
+                                            const u32* __restrict__ tok_start, const u32* __restrict__ tok_len,
+                                            const u8* __restrict__ denoised, const u64* __restrict__ text_off,
+                                            u8* __restrict__ text) {
     const int lane = threadIdx.x & 63;
-    u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= C) return;
     ChunkDesc c = chunks[i];
     u64 r = c.record;
     u8* dst = text + text_off[i];
@@ -3317,6 +3320,56 @@ __global__ __launch_bounds__(NT) void k_chunk_text_emit(const ChunkDesc* __restr
             if (span > len) d[len] = ' ';
         }
         base += __shfl(inc, 63, 64);
+    }
+}
+__global__ __launch_bounds__(NT) void k_chunk_text_emit(const ChunkDesc* __restrict__ chunks, u64 C,
+                                                         const u64* __restrict__ chunk_off, const u64* __restrict__ tok_off,
+                                                         const u64* __restrict__ den_off, const u32* __restrict__ tok_start,
+                                                         const u32* __restrict__ tok_len, const u8* __restrict__ denoised,
+                                                         const u64* __restrict__ text_off, u8* __restrict__ text) {
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i < C) chunk_text_emit_body(i, chunks, chunk_off, tok_off, den_off, tok_start, tok_len, denoised, text_off, text);
+}
+// The texts of a few descriptors in ONE launch (lengths, their scan, the texts: otherwise five launches and a
+// synchronise between them to size the text buffer).  One workgroup, a wavefront per descriptor at a time; the text
+// goes into a buffer of text_cap bytes, and the kernel tells the host the size and whether it fitted.
+constexpr u64 RENDER_SMALL_MAX = 256;
+struct GenLoadU64 {
+    const u64* v;
+    struct State {};
+    __device__ State begin() const { return State(); }
+    __device__ u64 at(const State&, u64 i) const { return v[i]; }
+    __device__ void once() const {}
+};
+__global__ __launch_bounds__(NT) void k_render_text_small(const ChunkDesc* __restrict__ chunks, u64 C, const u64* chunk_off,
+                                                           const u64* tok_off, const u64* den_off, const u32* tok_start,
+                                                           const u32* tok_len, const u8* denoised, u64* lens, u64* text_off,
+                                                           u8* text, u64 text_cap, u64* host_totals, u8* host_pack,
+                                                           u64 host_cap) {
+    __shared__ u64 smem[NT / 64];
+    const u64 wave = threadIdx.x >> 6;
+    for (u64 i = wave; i < C; i += NT / 64) chunk_text_len_body(i, chunks, chunk_off, tok_off, den_off, tok_len, lens);
+    __syncthreads();
+    const GenLoadU64 gen = {lens};
+    scan_small_body(smem, gen, C, text_off);
+    __syncthreads();
+    const u64 total = text_off[C];
+    const bool fits = total <= text_cap;
+    if (fits)
+        for (u64 i = wave; i < C; i += NT / 64)
+            chunk_text_emit_body(i, chunks, chunk_off, tok_off, den_off, tok_start, tok_len, denoised, text_off, text);
+    // for a caller in host memory: offsets and text into its page-locked block as well, when they fit
+    const u64 at_text = ((C + 1) * sizeof(u64) + 15) & ~(u64)15;
+    const bool packed = host_pack && fits && at_text + total <= host_cap;
+    if (packed) {
+        __syncthreads();
+        pack_copy(host_pack, text_off, (C + 1) * sizeof(u64));
+        pack_copy(host_pack + at_text, text, total);
+    }
+    if (threadIdx.x == 0) {
+        host_totals[4] = total;
+        host_totals[14] = packed ? 3 : fits ? 1 : 2;
+        __threadfence_system();
     }
 }
 
@@ -3508,6 +3561,10 @@ struct trp_ctx {
     // the first such batch).  small_io is set around the device call of such a batch only.
     u8* h_in = nullptr;
     u8* h_out = nullptr;
+    // Host entry points that want rendered texts in host memory set want_host_pack; the single-launch renderer then
+    // also leaves the offsets and the text in the upper half of h_out and says so in text_host_packed.
+    bool want_host_pack = false;
+    bool text_host_packed = false;
     struct SmallIO {
         bool on = false;
         bool gather = false;
@@ -4258,8 +4315,32 @@ static int render_text(trp_ctx* c, const ChunkDesc* chunks, u64 C, const u64* ch
                        uint64_t** d_text_offsets, uint64_t* n_text_bytes) {
     const trp_result& L = c->last;
     int rc;
+    c->text_host_packed = false;
     if ((rc = c->text_len.ensure((C + 1) * sizeof(u64)))) return rc;
     if ((rc = c->text_off.ensure((C + 2) * sizeof(u64)))) return rc;
+    if (C <= RENDER_SMALL_MAX && L.n_denoised <= ((u64)1 << 20) && !c->no_small) {
+        // a few descriptors over a small batch: one launch into a buffer that is usually large enough
+        if ((rc = c->text.ensure(((u64)4 << 20) + 16))) return rc;
+        c->h_totals[14] = 0;
+        u8* host_pack = nullptr;
+        if (c->want_host_pack) {
+            if (!c->h_out) HIPCHK(hipHostMalloc((void**)&c->h_out, H_OUT_BYTES, hipHostMallocDefault));
+            host_pack = c->h_out + SMALL_OUT_CAP;
+        }
+        hipLaunchKernelGGL(k_render_text_small, dim3(1), dim3(NT), 0, c->stream, chunks, C, chunk_off, L.tok_offsets,
+                           L.denoised_offsets, L.tok_start, L.tok_len, L.denoised, c->text_len.as<u64>(), c->text_off.as<u64>(),
+                           c->text.as<u8>(), c->text.cap - 16, c->h_totals, host_pack, SMALL_OUT_CAP);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->text_host_packed = c->h_totals[14] == 3;
+        if (c->h_totals[14] == 1 || c->h_totals[14] == 3) {
+            *d_text = c->text.as<u8>();
+            *d_text_offsets = c->text_off.as<u64>();
+            *n_text_bytes = c->h_totals[4];
+            return TRP_OK;
+        }
+        // (the text did not fit: the general way below sizes the buffer first)
+    }
     if (C) hipLaunchKernelGGL(k_chunk_text_len, dim3((unsigned)((C * 64 + NT - 1) / NT)), dim3(NT), 0, c->stream, chunks, C,
                               chunk_off, L.tok_offsets, L.denoised_offsets, L.tok_len, c->text_len.as<u64>());
     if ((rc = scan_u64(c, c->text_len.as<u64>(), C, c->text_off.as<u64>()))) return rc;
@@ -4314,7 +4395,16 @@ int trp_chunk_bodies_device(trp_ctx* c, const uint32_t* chunk_index, const uint3
     if ((rc = c->sel.ensure((2 * n + 2) * sizeof(u32)))) return rc;
     u32* d_idx = c->sel.as<u32>();
     u32* d_bud = d_idx + n;
-    if (n) {
+    if (n && 2 * n * sizeof(u32) <= SMALL_IN_CAP) {
+        // a short selection: through the page-locked block, which the kernel reads itself (no copy commands, and
+        // nothing to wait for: the block is not touched again before this call's own synchronise)
+        if (!c->h_in) HIPCHK(hipHostMalloc((void**)&c->h_in, SMALL_IN_CAP, hipHostMallocDefault));
+        u32* h = reinterpret_cast<u32*>(c->h_in);
+        memcpy(h, chunk_index, n * sizeof(u32));
+        memcpy(h + n, budget, n * sizeof(u32));
+        hipLaunchKernelGGL(k_body_desc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const ChunkDesc*>(L.chunks), L.n_chunks, h, h + n, n, c->heads.as<ChunkDesc>());
+    } else if (n) {
         HIPCHK(hipMemcpyAsync(d_idx, chunk_index, n * sizeof(u32), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(d_bud, budget, n * sizeof(u32), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_body_desc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
@@ -4669,7 +4759,7 @@ static int run_small_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offs
     int rc;
     *gathered = false;
     if (!c->h_in) HIPCHK(hipHostMalloc((void**)&c->h_in, SMALL_IN_CAP, hipHostMallocDefault));
-    if (gather && !c->h_out) HIPCHK(hipHostMalloc((void**)&c->h_out, SMALL_OUT_CAP, hipHostMallocDefault));
+    if (gather && !c->h_out) HIPCHK(hipHostMalloc((void**)&c->h_out, H_OUT_BYTES, hipHostMallocDefault));
     if ((rc = c->in_bytes.ensure(N + 64))) return rc;
     if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
     if (N) memcpy(c->h_in, bytes, N);
@@ -4772,15 +4862,28 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         uint8_t* d_ct = nullptr;
         uint64_t* d_cto = nullptr;
         uint64_t n_ct = 0;
-        if ((rc = render_text(c, reinterpret_cast<const ChunkDesc*>(d.chunks), d.n_chunks, d.chunk_offsets, &d_ct, &d_cto, &n_ct)))
-            return fail_free(rc);
-        if ((rc = grab((void**)&ctext->text, d_ct, n_ct))) return fail_free(rc);
-        if ((rc = grab((void**)&ctext->offsets, d_cto, (d.n_chunks + 1) * sizeof(u64)))) return fail_free(rc);
+        c->want_host_pack = true;
+        rc = render_text(c, reinterpret_cast<const ChunkDesc*>(d.chunks), d.n_chunks, d.chunk_offsets, &d_ct, &d_cto, &n_ct);
+        c->want_host_pack = false;
+        if (rc) return fail_free(rc);
+        if (c->text_host_packed) {   // both arrays lie in the page-locked block already
+            c->text_host_packed = false;
+            const u64 nb_off = (d.n_chunks + 1) * sizeof(u64);
+            ctext->text = (uint8_t*)host_pool().alloc(n_ct ? n_ct : 1);
+            ctext->offsets = (uint64_t*)host_pool().alloc(nb_off);
+            if (!ctext->text || !ctext->offsets) return fail_free(fail(TRP_E_ARG, "out of host memory"));
+            const u8* hp = c->h_out + SMALL_OUT_CAP;
+            memcpy(ctext->offsets, hp, nb_off);
+            if (n_ct) memcpy(ctext->text, hp + ((nb_off + 15) & ~(u64)15), n_ct);
+        } else {
+            if ((rc = grab((void**)&ctext->text, d_ct, n_ct))) return fail_free(rc);
+            if ((rc = grab((void**)&ctext->offsets, d_cto, (d.n_chunks + 1) * sizeof(u64)))) return fail_free(rc);
+        }
         ctext->n_bytes = n_ct;
     }
     if (pk.n) {
         if (!c->h_out) {
-            hipError_t e = hipHostMalloc((void**)&c->h_out, SMALL_OUT_CAP, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc((void**)&c->h_out, H_OUT_BYTES, hipHostMallocDefault);
             if (e != hipSuccess) return fail_free(fail(TRP_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)));
         }
         pk.dst = c->h_out;
@@ -4862,6 +4965,14 @@ static int texts_to_host(trp_ctx* c, const uint8_t* d_text, const uint64_t* d_of
     out->offsets = (uint64_t*)host_pool().alloc((n + 1) * sizeof(u64));
     out->text = (uint8_t*)host_pool().alloc(nbytes ? nbytes : 1);
     if (!out->offsets || !out->text) { trp_chunk_text_free(out); return fail(TRP_E_ARG, "out of host memory"); }
+    if (c->text_host_packed) {   // the renderer has left both arrays in the page-locked block already
+        c->text_host_packed = false;
+        const u8* hp = c->h_out + SMALL_OUT_CAP;
+        memcpy(out->offsets, hp, (n + 1) * sizeof(u64));
+        if (nbytes) memcpy(out->text, hp + (((n + 1) * sizeof(u64) + 15) & ~(u64)15), nbytes);
+        out->n_bytes = nbytes;
+        return TRP_OK;
+    }
     PackArgs pk;
     pk.n = 0;
     void* pk_dst[2];
@@ -4880,7 +4991,7 @@ static int texts_to_host(trp_ctx* c, const uint8_t* d_text, const uint64_t* d_of
     fetch(out->offsets, d_off, (n + 1) * sizeof(u64));
     fetch(out->text, d_text, nbytes);
     if (e == hipSuccess && pk.n) {
-        if (!c->h_out) e = hipHostMalloc((void**)&c->h_out, SMALL_OUT_CAP, hipHostMallocDefault);
+        if (!c->h_out) e = hipHostMalloc((void**)&c->h_out, H_OUT_BYTES, hipHostMallocDefault);
         if (e == hipSuccess) {
             pk.dst = c->h_out;
             hipLaunchKernelGGL(k_pack_small, dim3((unsigned)pk.n), dim3(NT), 0, c->stream, pk);
@@ -4906,6 +5017,7 @@ int trp_bm25_texts(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     uint8_t* d_text = nullptr;
     uint64_t* d_off = nullptr;
     uint64_t nbytes = 0;
+    c->text_host_packed = false;
     if ((rc = trp_bm25_texts_device(c, doc_offsets, n_docs, max_tokens, newline, &d_text, &d_off, &nbytes))) return rc;
     return texts_to_host(c, d_text, d_off, n_docs, nbytes, out);
 }
@@ -4923,7 +5035,10 @@ int trp_head_tokens_text(trp_ctx* c, const uint8_t* bytes, const uint64_t* offse
     uint8_t* d_text = nullptr;
     uint64_t* d_off = nullptr;
     uint64_t nbytes = 0;
-    if ((rc = trp_head_tokens_text_device(c, max_tokens, &d_text, &d_off, &nbytes))) return rc;
+    c->want_host_pack = true;
+    rc = trp_head_tokens_text_device(c, max_tokens, &d_text, &d_off, &nbytes);
+    c->want_host_pack = false;
+    if (rc) return rc;
     return texts_to_host(c, d_text, d_off, R, nbytes, out);
 }
 
@@ -4939,7 +5054,10 @@ int trp_chunk_bodies(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, 
     uint8_t* d_text = nullptr;
     uint64_t* d_off = nullptr;
     uint64_t nbytes = 0;
-    if ((rc = trp_chunk_bodies_device(c, chunk_index, budget, n, &d_text, &d_off, &nbytes))) return rc;
+    c->want_host_pack = true;
+    rc = trp_chunk_bodies_device(c, chunk_index, budget, n, &d_text, &d_off, &nbytes);
+    c->want_host_pack = false;
+    if (rc) return rc;
     return texts_to_host(c, d_text, d_off, n, nbytes, out);
 }
 
