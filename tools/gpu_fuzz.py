@@ -71,6 +71,22 @@ def main():
             print("MISMATCH seed=%d nrec=%d enabled=%s ratio=%s md=%s mwt=%d ov=%s sft=%d\n%s"
                   % (seed, nrec, enabled, ratio, md, mwt, ov, sft, e), flush=True)
             sys.exit(1)
+        if args.small:
+            # the texts of the chunks as well (descriptors + chunk text rendered on the GPU, what a table of chunks asks for)
+            sel = ctx.preprocess_batch_select(data, offs, T.DenoiserConfig(enabled, ratio, md),
+                                              T.ChunkingStrategy(max_window_tokens=mwt, overlap_tokens=list(ov),
+                                                                 summary_fallback_tokens=sft),
+                                              T.OUT_CHUNKS | T.OUT_CHUNK_TEXT)
+            o = sel.chunk_text_offsets
+            ok = len(o) == exp.n_chunks + 1
+            for c in range(exp.n_chunks if ok else 0):
+                if sel.chunk_text_bytes[int(o[c]):int(o[c + 1])].tobytes() != exp.chunk_text(c):
+                    ok = False
+                    break
+            if not ok:
+                print("CHUNK TEXT MISMATCH seed=%d nrec=%d enabled=%s ratio=%s md=%s mwt=%d ov=%s sft=%d"
+                      % (seed, nrec, enabled, ratio, md, mwt, ov, sft), flush=True)
+                sys.exit(1)
         n += 1
         seed += 1
         if n % 20 == 0:
