@@ -3050,191 +3050,12 @@ __global__ __launch_bounds__(NT) void k_chunks_small(GenChunkCounts gen, u64 R, 
     chunk_emit_body(0u, 1u, chunk_off, gen.tok_off, R, cfg, capacity, chunks, gen.totals, host_totals);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_small_batch: the whole path in one launch, for batches of a few tiles
-// ---------------------------------------------------------------------------------------------------
-// A batch of a few kilobytes is bound by the number of dependent launches (eight of them, each a few
-// microseconds, for microseconds of work).  Up to SMALL_MAX_TILES tiles and SMALL_MAX_RECORDS records are
-// therefore handled by ONE workgroup that runs the bodies of the kernels above one after the other, with a
-// workgroup barrier where the full path has a kernel boundary.  Same code, same arrays, same results; when the
-// tile seeds cannot be settled from the windows next to the tiles the batch says so in its totals exactly as the
-// full path does, and the host runs it again there.
-constexpr u64 SMALL_MAX_TILES = 2;        // 32 KiB of text: one workgroup takes ~13 us a tile, the kernel sequence ~50 us in all
-// (A batch from host memory has the same limit: beyond two tiles the kernel sequence with its short result arrays
-// packed by one launch, k_pack_small, is as fast - 88 us against 121 us for 64 KiB.)
-constexpr u64 SMALL_HOST_MAX_TILES = SMALL_MAX_TILES;
-constexpr u64 SMALL_MAX_RECORDS = 4096;
-struct SmallArgs {
-    const u8* bytes;
-    const u64* offsets;
-    u64 R, N;
-    DevCfg cfg;
-    RatioArg ratio;
-    u32 force_open;
-    // working arrays (see PathBufs)
-    u32 *rec_lo, *rec_lo_w;
-    J* seedJ;
-    S* seedS;
-    void* plan;
-    u64* g3list;
-    u64 g3cap;
-    u32 *tile_bytes, *tile_toks, *tile_flags;
-    u64 *packed, *tile_base, *counts, *totals;
-    // results
-    u8* denoised;
-    u64 *den_off, *tok_off, *chunk_off;
-    u8* dropped;
-    u32 *tok_start, *tok_len;
-    ChunkDesc* chunks;
-    u64 chunk_cap;
-    u64* host_totals;
-    u64 seq;
-    // A batch that comes from host memory (null otherwise): its text and offsets lie in page-locked host memory and
-    // are first copied to `bytes` / `offsets` (stage_bytes / stage_offsets are the same arrays, writable); at the
-    // end the results are gathered into one page-locked block (pack_layout) when they fit.
-    const u8* src_bytes;
-    const u64* src_offsets;
-    u8* stage_bytes;
-    u64* stage_offsets;
-    u8* host_out;
-    u64 host_out_cap;
-    u32 outputs;
-};
-// Where the result arrays of a small host batch lie in the page-locked block, every array on a 16-byte boundary.
-struct PackLayout {
-    u64 den_off, tok_off, chunk_off, chunks, tok_start, tok_len, denoised, dropped, total;
-};
-__host__ __device__ inline PackLayout pack_layout(u64 R, u64 n_den, u64 n_tok, u64 n_chunks, u32 outputs) {
-    PackLayout L;
-    u64 p = 0;
-    auto take = [&p](u64 bytes) { const u64 at = p; p += (bytes + 15) & ~(u64)15; return at; };
-    L.den_off = take((R + 1) * sizeof(u64));
-    L.tok_off = take((R + 1) * sizeof(u64));
-    L.chunk_off = take((R + 1) * sizeof(u64));
-    L.chunks = take((outputs & TRP_OUT_CHUNKS) ? n_chunks * sizeof(ChunkDesc) : 0);
-    L.tok_start = take((outputs & TRP_OUT_TOKENS) ? n_tok * sizeof(u32) : 0);
-    L.tok_len = take((outputs & TRP_OUT_TOKENS) ? n_tok * sizeof(u32) : 0);
-    L.denoised = take((outputs & TRP_OUT_TEXT) ? n_den : 0);
-    L.dropped = take(R);
-    L.total = p;
-    return L;
-}
 // n bytes from a 16-byte aligned device array to a 16-byte aligned place in host memory, by the whole workgroup.
 __device__ inline void pack_copy(u8* __restrict__ dst, const void* __restrict__ src_, u64 n) {
     const u8* src = reinterpret_cast<const u8*>(src_);
     const u64 q = n >> 4;
     for (u64 i = threadIdx.x; i < q; i += NT) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
     for (u64 i = (q << 4) + threadIdx.x; i < n; i += NT) dst[i] = src[i];
-}
-constexpr u64 SMALL_OUT_CAP = (u64)1 << 20;   // page-locked block for the results of a small host batch ...
-constexpr u64 H_OUT_BYTES = 2 * SMALL_OUT_CAP;  // ... and as much again behind it for rendered texts (k_render_text_small)
-// Several short device arrays into one page-locked host block with one launch: the per-record arrays of a host
-// batch are a few kilobytes each, and a copy command to pageable memory costs 20 us apiece.
-constexpr int PACK_MAX = 12;
-struct PackArgs {
-    const void* src[PACK_MAX];
-    u64 bytes[PACK_MAX];
-    u64 at[PACK_MAX];     // 16-byte aligned offsets into dst
-    int n;
-    u8* dst;
-};
-__global__ __launch_bounds__(NT) void k_pack_small(PackArgs a) {
-    for (int i = blockIdx.x; i < a.n; i += gridDim.x) pack_copy(a.dst + a.at[i], a.src[i], a.bytes[i]);
-}
-constexpr u64 SMALL_IN_CAP = (u64)256 << 10;   // page-locked block for a small host batch, or for the offsets of a larger one
-static_assert(SMALL_IN_CAP >= SMALL_HOST_MAX_TILES * TILE + 64 + (SMALL_MAX_RECORDS + 1) * sizeof(u64), "small batch must fit");
-union SmallShared {
-    SeedShared seed;
-    PlanShared plan;
-    CountShared count;
-    EmitShared emit[EMIT_WAVES];
-    G3SolveShared g3[NT / 64];
-    u64 scan[NT / 64];
-};
-static_assert(EMIT_WAVES == NT / 64, "the emit body takes one sub-tile per wavefront of the workgroup");
-
-template <int MODE>   // 0: denoiser, 1: normalize_inline_whitespace, 2: denoiser off (pass-through)
-__global__ __launch_bounds__(NT) void k_small_batch(SmallArgs a) {
-    __shared__ SmallShared sh;
-    __shared__ UniShared uni;
-    const u64 R = a.R, N = a.N;
-    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
-    const PlanMem plan = plan_view(a.plan, nB);
-    const int wave = threadIdx.x >> 6;
-    if (a.src_offsets) {   // uniform: the batch comes from page-locked host memory (the block has slack behind the text)
-        for (u64 i = threadIdx.x; i * 16 < N; i += NT)
-            reinterpret_cast<uint4*>(a.stage_bytes)[i] = reinterpret_cast<const uint4*>(a.src_bytes)[i];
-        for (u64 i = threadIdx.x; i <= R; i += NT) a.stage_offsets[i] = a.src_offsets[i];
-        __syncthreads();
-    }
-    for (u32 vb = 0; (u64)vb * NT <= R; vb++)
-        rec_lo_body(vb, a.offsets, R, N, nT, nW, a.rec_lo, a.rec_lo_w, a.totals, a.seq);
-    stage_tables(uni);
-    __syncthreads();
-    if (nT) {   // uniform
-        if (MODE != 2) {
-            u32* const open_count = reinterpret_cast<u32*>(a.totals + 8);   // zeroed with the totals
-            for (u32 vb = 0; (u64)vb * SEED_TPW * (NT / 64) < nT; vb++)   // (a wavefront shares nothing with the others)
-                seed_body<MODE == 1>(sh.seed, uni, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, nT, a.force_open, a.seedJ,
-                                     a.seedS, open_count);
-            __syncthreads();
-            for (u32 vb = 0; vb < nT; vb++) {
-                plan_body<MODE == 1>(sh.plan, uni, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, a.seedJ, a.seedS, a.cfg, a.ratio,
-                                     plan, a.g3list, a.g3cap, a.totals + 6, a.tile_bytes, a.tile_toks, a.tile_flags, 0u);
-                __syncthreads();
-            }
-            gate3_solve_body(sh.g3[wave], (u32)wave, NT / 64, a.bytes, a.offsets, a.rec_lo, R, N, nB, a.cfg, plan, a.g3list,
-                             a.totals + 6, a.g3cap, a.tile_bytes, a.tile_toks, a.totals, a.denoised);
-        } else {
-            for (u32 vb = 0; vb < nT; vb++) {
-                count_tokens_body(sh.count, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, plan, a.tile_bytes, a.tile_toks,
-                                  a.tile_flags);
-                __syncthreads();
-            }
-        }
-        __syncthreads();
-        {
-            const GenTiles gen = {a.tile_bytes, a.tile_toks, a.tile_flags, a.packed};
-            scan_small_body(sh.scan, gen, nW, a.tile_base);
-        }
-        __syncthreads();
-        for (u32 vb = 0; (u64)vb * EMIT_WAVES < nW; vb++)   // (wavefronts are independent of each other here too)
-            emit_body<MODE == 2, EMIT_WAVES>(sh.emit, vb, a.bytes, a.offsets, a.rec_lo_w, R, N, nB, nW, plan, a.tile_base,
-                                             MODE == 2 ? (u8*)nullptr : a.denoised, a.tok_start, a.tok_len, a.den_off,
-                                             a.tok_off, 0u);
-        __syncthreads();
-    }
-    {
-        GenChunkCounts gen;
-        gen.tile_base = a.tile_base; gen.nW = nW; gen.rec_lo_w = a.rec_lo_w; gen.R = R; gen.N = N;
-        gen.passthrough = MODE == 2 ? 1 : 0; gen.cfg = a.cfg;
-        gen.den_off = a.den_off; gen.tok_off = a.tok_off; gen.totals = a.totals; gen.counts = a.counts; gen.dropped = a.dropped;
-        scan_small_body(sh.scan, gen, R, a.chunk_off);
-    }
-    __syncthreads();
-    chunk_emit_body(0u, 1u, a.chunk_off, a.tok_off, R, a.cfg, a.chunk_cap, a.chunks, a.totals, a.host_totals);
-    if (a.host_out) {   // uniform
-        __syncthreads();
-        // nothing to gather from a batch that the host will run again (open tiles, a list or the descriptor array too
-        // small) or reject (offsets)
-        const u64 n_den = a.totals[0], n_tok = a.totals[1], C = a.chunk_off[R];
-        const bool again = a.totals[5] != 0 || (u32)a.totals[8] != 0 || C > a.chunk_cap || a.totals[9] == a.seq;
-        const PackLayout L = pack_layout(R, n_den, n_tok, C, a.outputs);
-        if (!again && L.total <= a.host_out_cap) {
-            u8* const o = a.host_out;
-            pack_copy(o + L.den_off, a.den_off, (R + 1) * sizeof(u64));
-            pack_copy(o + L.tok_off, a.tok_off, (R + 1) * sizeof(u64));
-            pack_copy(o + L.chunk_off, a.chunk_off, (R + 1) * sizeof(u64));
-            if (a.outputs & TRP_OUT_CHUNKS) pack_copy(o + L.chunks, a.chunks, C * sizeof(ChunkDesc));
-            if (a.outputs & TRP_OUT_TOKENS) {
-                pack_copy(o + L.tok_start, a.tok_start, n_tok * sizeof(u32));
-                pack_copy(o + L.tok_len, a.tok_len, n_tok * sizeof(u32));
-            }
-            if (a.outputs & TRP_OUT_TEXT) pack_copy(o + L.denoised, MODE == 2 ? a.bytes : a.denoised, n_den);
-            pack_copy(o + L.dropped, a.dropped, R);
-            if (threadIdx.x == 0) a.host_totals[10] = a.seq;   // "gathered": read by the host once the kernel has ended
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3370,6 +3191,213 @@ __global__ __launch_bounds__(NT) void k_render_text_small(const ChunkDesc* __res
         host_totals[4] = total;
         host_totals[14] = packed ? 3 : fits ? 1 : 2;
         __threadfence_system();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_small_batch: the whole path in one launch, for batches of a few tiles
+// ---------------------------------------------------------------------------------------------------
+// A batch of a few kilobytes is bound by the number of dependent launches (eight of them, each a few
+// microseconds, for microseconds of work).  Up to SMALL_MAX_TILES tiles and SMALL_MAX_RECORDS records are
+// therefore handled by ONE workgroup that runs the bodies of the kernels above one after the other, with a
+// workgroup barrier where the full path has a kernel boundary.  Same code, same arrays, same results; when the
+// tile seeds cannot be settled from the windows next to the tiles the batch says so in its totals exactly as the
+// full path does, and the host runs it again there.
+constexpr u64 SMALL_MAX_TILES = 2;        // 32 KiB of text: one workgroup takes ~13 us a tile, the kernel sequence ~50 us in all
+// (A batch from host memory has the same limit: beyond two tiles the kernel sequence with its short result arrays
+// packed by one launch, k_pack_small, is as fast - 88 us against 121 us for 64 KiB.)
+constexpr u64 SMALL_HOST_MAX_TILES = SMALL_MAX_TILES;
+constexpr u64 SMALL_MAX_RECORDS = 4096;
+struct SmallArgs {
+    const u8* bytes;
+    const u64* offsets;
+    u64 R, N;
+    DevCfg cfg;
+    RatioArg ratio;
+    u32 force_open;
+    // working arrays (see PathBufs)
+    u32 *rec_lo, *rec_lo_w;
+    J* seedJ;
+    S* seedS;
+    void* plan;
+    u64* g3list;
+    u64 g3cap;
+    u32 *tile_bytes, *tile_toks, *tile_flags;
+    u64 *packed, *tile_base, *counts, *totals;
+    // results
+    u8* denoised;
+    u64 *den_off, *tok_off, *chunk_off;
+    u8* dropped;
+    u32 *tok_start, *tok_len;
+    ChunkDesc* chunks;
+    u64 chunk_cap;
+    u64* host_totals;
+    u64 seq;
+    // A batch that comes from host memory (null otherwise): its text and offsets lie in page-locked host memory and
+    // are first copied to `bytes` / `offsets` (stage_bytes / stage_offsets are the same arrays, writable); at the
+    // end the results are gathered into one page-locked block (pack_layout) when they fit.
+    const u8* src_bytes;
+    const u64* src_offsets;
+    u8* stage_bytes;
+    u64* stage_offsets;
+    u8* host_out;
+    u64 host_out_cap;
+    u32 outputs;
+    // with TRP_OUT_CHUNK_TEXT among the outputs: the chunk texts as well (lengths, their offsets, the text buffer and
+    // its capacity), rendered behind the descriptors when there are at most RENDER_SMALL_MAX of them
+    u64 *text_len, *text_off;
+    u8* text;
+    u64 text_cap;
+};
+// Where the result arrays of a small host batch lie in the page-locked block, every array on a 16-byte boundary.
+struct PackLayout {
+    u64 den_off, tok_off, chunk_off, chunks, tok_start, tok_len, denoised, dropped, total;
+};
+__host__ __device__ inline PackLayout pack_layout(u64 R, u64 n_den, u64 n_tok, u64 n_chunks, u32 outputs) {
+    PackLayout L;
+    u64 p = 0;
+    auto take = [&p](u64 bytes) { const u64 at = p; p += (bytes + 15) & ~(u64)15; return at; };
+    L.den_off = take((R + 1) * sizeof(u64));
+    L.tok_off = take((R + 1) * sizeof(u64));
+    L.chunk_off = take((R + 1) * sizeof(u64));
+    L.chunks = take((outputs & TRP_OUT_CHUNKS) ? n_chunks * sizeof(ChunkDesc) : 0);
+    L.tok_start = take((outputs & TRP_OUT_TOKENS) ? n_tok * sizeof(u32) : 0);
+    L.tok_len = take((outputs & TRP_OUT_TOKENS) ? n_tok * sizeof(u32) : 0);
+    L.denoised = take((outputs & TRP_OUT_TEXT) ? n_den : 0);
+    L.dropped = take(R);
+    L.total = p;
+    return L;
+}
+constexpr u64 SMALL_OUT_CAP = (u64)1 << 20;   // page-locked block for the results of a small host batch ...
+constexpr u64 H_OUT_BYTES = 2 * SMALL_OUT_CAP;  // ... and as much again behind it for rendered texts (k_render_text_small)
+// Several short device arrays into one page-locked host block with one launch: the per-record arrays of a host
+// batch are a few kilobytes each, and a copy command to pageable memory costs 20 us apiece.
+constexpr int PACK_MAX = 12;
+struct PackArgs {
+    const void* src[PACK_MAX];
+    u64 bytes[PACK_MAX];
+    u64 at[PACK_MAX];     // 16-byte aligned offsets into dst
+    int n;
+    u8* dst;
+};
+__global__ __launch_bounds__(NT) void k_pack_small(PackArgs a) {
+    for (int i = blockIdx.x; i < a.n; i += gridDim.x) pack_copy(a.dst + a.at[i], a.src[i], a.bytes[i]);
+}
+constexpr u64 SMALL_IN_CAP = (u64)256 << 10;   // page-locked block for a small host batch, or for the offsets of a larger one
+static_assert(SMALL_IN_CAP >= SMALL_HOST_MAX_TILES * TILE + 64 + (SMALL_MAX_RECORDS + 1) * sizeof(u64), "small batch must fit");
+union SmallShared {
+    SeedShared seed;
+    PlanShared plan;
+    CountShared count;
+    EmitShared emit[EMIT_WAVES];
+    G3SolveShared g3[NT / 64];
+    u64 scan[NT / 64];
+};
+static_assert(EMIT_WAVES == NT / 64, "the emit body takes one sub-tile per wavefront of the workgroup");
+
+template <int MODE>   // 0: denoiser, 1: normalize_inline_whitespace, 2: denoiser off (pass-through)
+__global__ __launch_bounds__(NT) void k_small_batch(SmallArgs a) {
+    __shared__ SmallShared sh;
+    __shared__ UniShared uni;
+    const u64 R = a.R, N = a.N;
+    const u64 nB = (N + BLOCK - 1) / BLOCK, nT = (N + TILE - 1) / TILE, nW = (N + SUB - 1) / SUB;
+    const PlanMem plan = plan_view(a.plan, nB);
+    const int wave = threadIdx.x >> 6;
+    if (a.src_offsets) {   // uniform: the batch comes from page-locked host memory (the block has slack behind the text)
+        for (u64 i = threadIdx.x; i * 16 < N; i += NT)
+            reinterpret_cast<uint4*>(a.stage_bytes)[i] = reinterpret_cast<const uint4*>(a.src_bytes)[i];
+        for (u64 i = threadIdx.x; i <= R; i += NT) a.stage_offsets[i] = a.src_offsets[i];
+        __syncthreads();
+    }
+    for (u32 vb = 0; (u64)vb * NT <= R; vb++)
+        rec_lo_body(vb, a.offsets, R, N, nT, nW, a.rec_lo, a.rec_lo_w, a.totals, a.seq);
+    stage_tables(uni);
+    __syncthreads();
+    if (nT) {   // uniform
+        if (MODE != 2) {
+            u32* const open_count = reinterpret_cast<u32*>(a.totals + 8);   // zeroed with the totals
+            for (u32 vb = 0; (u64)vb * SEED_TPW * (NT / 64) < nT; vb++)   // (a wavefront shares nothing with the others)
+                seed_body<MODE == 1>(sh.seed, uni, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, nT, a.force_open, a.seedJ,
+                                     a.seedS, open_count);
+            __syncthreads();
+            for (u32 vb = 0; vb < nT; vb++) {
+                plan_body<MODE == 1>(sh.plan, uni, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, a.seedJ, a.seedS, a.cfg, a.ratio,
+                                     plan, a.g3list, a.g3cap, a.totals + 6, a.tile_bytes, a.tile_toks, a.tile_flags, 0u);
+                __syncthreads();
+            }
+            gate3_solve_body(sh.g3[wave], (u32)wave, NT / 64, a.bytes, a.offsets, a.rec_lo, R, N, nB, a.cfg, plan, a.g3list,
+                             a.totals + 6, a.g3cap, a.tile_bytes, a.tile_toks, a.totals, a.denoised);
+        } else {
+            for (u32 vb = 0; vb < nT; vb++) {
+                count_tokens_body(sh.count, vb, a.bytes, a.offsets, a.rec_lo, R, N, nB, plan, a.tile_bytes, a.tile_toks,
+                                  a.tile_flags);
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        {
+            const GenTiles gen = {a.tile_bytes, a.tile_toks, a.tile_flags, a.packed};
+            scan_small_body(sh.scan, gen, nW, a.tile_base);
+        }
+        __syncthreads();
+        for (u32 vb = 0; (u64)vb * EMIT_WAVES < nW; vb++)   // (wavefronts are independent of each other here too)
+            emit_body<MODE == 2, EMIT_WAVES>(sh.emit, vb, a.bytes, a.offsets, a.rec_lo_w, R, N, nB, nW, plan, a.tile_base,
+                                             MODE == 2 ? (u8*)nullptr : a.denoised, a.tok_start, a.tok_len, a.den_off,
+                                             a.tok_off, 0u);
+        __syncthreads();
+    }
+    {
+        GenChunkCounts gen;
+        gen.tile_base = a.tile_base; gen.nW = nW; gen.rec_lo_w = a.rec_lo_w; gen.R = R; gen.N = N;
+        gen.passthrough = MODE == 2 ? 1 : 0; gen.cfg = a.cfg;
+        gen.den_off = a.den_off; gen.tok_off = a.tok_off; gen.totals = a.totals; gen.counts = a.counts; gen.dropped = a.dropped;
+        scan_small_body(sh.scan, gen, R, a.chunk_off);
+    }
+    __syncthreads();
+    chunk_emit_body(0u, 1u, a.chunk_off, a.tok_off, R, a.cfg, a.chunk_cap, a.chunks, a.totals, a.host_totals);
+    if (a.host_out) {   // uniform
+        __syncthreads();
+        // nothing to gather from a batch that the host will run again (open tiles, a list or the descriptor array too
+        // small) or reject (offsets)
+        const u64 n_den = a.totals[0], n_tok = a.totals[1], C = a.chunk_off[R];
+        const bool again = a.totals[5] != 0 || (u32)a.totals[8] != 0 || C > a.chunk_cap || a.totals[9] == a.seq;
+        const PackLayout L = pack_layout(R, n_den, n_tok, C, a.outputs);
+        if (!again && L.total <= a.host_out_cap) {
+            u8* const o = a.host_out;
+            pack_copy(o + L.den_off, a.den_off, (R + 1) * sizeof(u64));
+            pack_copy(o + L.tok_off, a.tok_off, (R + 1) * sizeof(u64));
+            pack_copy(o + L.chunk_off, a.chunk_off, (R + 1) * sizeof(u64));
+            if (a.outputs & TRP_OUT_CHUNKS) pack_copy(o + L.chunks, a.chunks, C * sizeof(ChunkDesc));
+            if (a.outputs & TRP_OUT_TOKENS) {
+                pack_copy(o + L.tok_start, a.tok_start, n_tok * sizeof(u32));
+                pack_copy(o + L.tok_len, a.tok_len, n_tok * sizeof(u32));
+            }
+            if (a.outputs & TRP_OUT_TEXT) pack_copy(o + L.denoised, MODE == 2 ? a.bytes : a.denoised, n_den);
+            pack_copy(o + L.dropped, a.dropped, R);
+            if (threadIdx.x == 0) a.host_totals[10] = a.seq;   // "gathered": read by the host once the kernel has ended
+            if ((a.outputs & TRP_OUT_CHUNK_TEXT) && C <= RENDER_SMALL_MAX) {   // uniform
+                // the chunk texts behind the arrays (k_render_text_small's steps)
+                const u8* const den = MODE == 2 ? a.bytes : a.denoised;
+                __syncthreads();
+                for (u64 i = (u64)wave; i < C; i += NT / 64)
+                    chunk_text_len_body(i, a.chunks, a.chunk_off, a.tok_off, a.den_off, a.tok_len, a.text_len);
+                __syncthreads();
+                const GenLoadU64 gen = {a.text_len};
+                scan_small_body(sh.scan, gen, C, a.text_off);
+                __syncthreads();
+                const u64 total = a.text_off[C];
+                const u64 at_text = ((C + 1) * sizeof(u64) + 15) & ~(u64)15;
+                if (total <= a.text_cap && L.total + at_text + total <= a.host_out_cap) {
+                    for (u64 i = (u64)wave; i < C; i += NT / 64)
+                        chunk_text_emit_body(i, a.chunks, a.chunk_off, a.tok_off, a.den_off, a.tok_start, a.tok_len, den, a.text_off,
+                                             a.text);
+                    __syncthreads();
+                    pack_copy(o + L.total, a.text_off, (C + 1) * sizeof(u64));
+                    pack_copy(o + L.total + at_text, a.text, total);
+                    if (threadIdx.x == 0) { a.host_totals[12] = a.seq; a.host_totals[13] = total; }
+                }
+            }
+        }
     }
 }
 
@@ -3903,7 +3931,13 @@ static int enqueue_path(trp_ctx* c, hipStream_t st, const PathBufs& B, const uin
             a.src_offsets = reinterpret_cast<const u64*>(c->h_in + SMALL_HOST_MAX_TILES * TILE + 64);
             a.stage_bytes = const_cast<u8*>(d_bytes);          // the context's own in_bytes / in_offsets
             a.stage_offsets = const_cast<u64*>(d_offsets);
-            if (c->small_io.gather) { a.host_out = c->h_out; a.host_out_cap = SMALL_OUT_CAP; a.outputs = c->small_io.outputs; }
+            if (c->small_io.gather) {
+                a.host_out = c->h_out; a.host_out_cap = SMALL_OUT_CAP; a.outputs = c->small_io.outputs;
+                if (a.outputs & TRP_OUT_CHUNK_TEXT) {   // (sized by run_small_host)
+                    a.text_len = c->text_len.as<u64>(); a.text_off = c->text_off.as<u64>();
+                    a.text = c->text.as<u8>(); a.text_cap = c->text.cap - 16;
+                }
+            }
         }
         if (pass) hipLaunchKernelGGL(k_small_batch<2>, dim3(1), dim3(NT), 0, st, a);
         else if (dc.normalize) hipLaunchKernelGGL(k_small_batch<1>, dim3(1), dim3(NT), 0, st, a);
@@ -4762,9 +4796,15 @@ static int run_small_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offs
     if (gather && !c->h_out) HIPCHK(hipHostMalloc((void**)&c->h_out, H_OUT_BYTES, hipHostMallocDefault));
     if ((rc = c->in_bytes.ensure(N + 64))) return rc;
     if ((rc = c->in_offsets.ensure((R + 1) * sizeof(u64)))) return rc;
+    if (gather && (outputs & TRP_OUT_CHUNK_TEXT)) {
+        if ((rc = c->text_len.ensure((RENDER_SMALL_MAX + 1) * sizeof(u64)))) return rc;
+        if ((rc = c->text_off.ensure((RENDER_SMALL_MAX + 2) * sizeof(u64)))) return rc;
+        if ((rc = c->text.ensure(((u64)4 << 20) + 16))) return rc;
+    }
     if (N) memcpy(c->h_in, bytes, N);
     memcpy(c->h_in + SMALL_HOST_MAX_TILES * TILE + 64, offsets, (R + 1) * sizeof(u64));
     c->h_totals[10] = 0;
+    c->h_totals[12] = 0;
     c->small_io.on = true;
     c->small_io.gather = gather;
     c->small_io.outputs = outputs;
@@ -4862,6 +4902,18 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
         uint8_t* d_ct = nullptr;
         uint64_t* d_cto = nullptr;
         uint64_t n_ct = 0;
+        const u64 nb_off0 = (d.n_chunks + 1) * sizeof(u64);
+        if (gathered && c->h_totals[12] != 0) {
+            // the single launch has rendered the texts as well: they lie behind the gathered arrays
+            n_ct = c->h_totals[13];
+            ctext->text = (uint8_t*)host_pool().alloc(n_ct ? n_ct : 1);
+            ctext->offsets = (uint64_t*)host_pool().alloc(nb_off0);
+            if (!ctext->text || !ctext->offsets) return fail_free(fail(TRP_E_ARG, "out of host memory"));
+            const u8* hp = c->h_out + L.total;
+            memcpy(ctext->offsets, hp, nb_off0);
+            if (n_ct) memcpy(ctext->text, hp + ((nb_off0 + 15) & ~(u64)15), n_ct);
+            ctext->n_bytes = n_ct;
+        } else {
         c->want_host_pack = true;
         rc = render_text(c, reinterpret_cast<const ChunkDesc*>(d.chunks), d.n_chunks, d.chunk_offsets, &d_ct, &d_cto, &n_ct);
         c->want_host_pack = false;
@@ -4880,6 +4932,7 @@ static int run_host(trp_ctx* c, const uint8_t* bytes, const uint64_t* offsets, u
             if ((rc = grab((void**)&ctext->offsets, d_cto, (d.n_chunks + 1) * sizeof(u64)))) return fail_free(rc);
         }
         ctext->n_bytes = n_ct;
+        }
     }
     if (pk.n) {
         if (!c->h_out) {
