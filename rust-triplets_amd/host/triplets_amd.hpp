@@ -119,19 +119,30 @@ inline std::vector<trp_denoiser> more_of(const ChunkingStrategy& st) {
 // Host-side view of one batch result (owns the arrays).
 class BatchResult {
 public:
-    BatchResult() { std::memset(&r_, 0, sizeof r_); }
-    ~BatchResult() { trp_result_free(&r_); }
+    BatchResult() { std::memset(&r_, 0, sizeof r_); std::memset(&ct_, 0, sizeof ct_); }
+    ~BatchResult() { trp_result_free(&r_); trp_chunk_text_free(&ct_); }
     BatchResult(const BatchResult&) = delete;
     BatchResult& operator=(const BatchResult&) = delete;
-    BatchResult(BatchResult&& o) noexcept : r_(o.r_), weight_(o.weight_) { std::memset(&o.r_, 0, sizeof o.r_); }
+    BatchResult(BatchResult&& o) noexcept : r_(o.r_), ct_(o.ct_), weight_(o.weight_) {
+        std::memset(&o.r_, 0, sizeof o.r_);
+        std::memset(&o.ct_, 0, sizeof o.ct_);
+    }
     BatchResult& operator=(BatchResult&& o) noexcept {
         if (this != &o) {
             trp_result_free(&r_);
+            trp_chunk_text_free(&ct_);
             r_ = o.r_;
+            ct_ = o.ct_;
             weight_ = o.weight_;
             std::memset(&o.r_, 0, sizeof o.r_);
+            std::memset(&o.ct_, 0, sizeof o.ct_);
         }
         return *this;
+    }
+    // the text of chunk i as the GPU rendered it (results made with TRP_OUT_CHUNK_TEXT)
+    bool has_chunk_text() const { return ct_.offsets != nullptr; }
+    std::string_view chunk_text(size_t i) const {
+        return {reinterpret_cast<const char*>(ct_.text) + ct_.offsets[i], (size_t)(ct_.offsets[i + 1] - ct_.offsets[i])};
     }
 
     const trp_result& raw() const { return r_; }
@@ -164,7 +175,9 @@ public:
                 rc.view.strategy = "head";
                 rc.view.weight = weight_;
             }
-            if (c.kind == 0 && c.tok_begin == 0 && c.tok_end == total && c.span == total) {
+            if (has_chunk_text()) {
+                rc.text = std::string(chunk_text(i));   // rendered on the GPU: neither the text nor the tokens came back
+            } else if (c.kind == 0 && c.tok_begin == 0 && c.tok_end == total && c.span == total) {
                 rc.text = std::string(text(r));   // single window: preprocessed text verbatim
             } else {
                 for (uint32_t k = c.tok_begin; k < c.tok_end; k++) {
@@ -180,6 +193,7 @@ public:
 private:
     friend class BatchPreprocessor;
     trp_result r_;
+    trp_chunk_text ct_;
     float weight_ = 0.35f;
 };
 
@@ -213,7 +227,8 @@ public:
         out.weight_ = st.summary_fallback_weight;
         auto more = detail::more_of(st);
         check(trp_preprocess_batch_fold(ctx_.raw(), bytes.data(), offs.data(), sections.size(), &c, more.data(),
-                                        (uint32_t)more.size(), outputs, &out.r_, nullptr));
+                                        (uint32_t)more.size(), outputs, &out.r_,
+                                        (outputs & TRP_OUT_CHUNK_TEXT) ? &out.ct_ : nullptr));
         return out;
     }
     BatchResult run_packed(const uint8_t* bytes, const uint64_t* offsets, size_t n, const ChunkingStrategy& st) {
@@ -776,7 +791,9 @@ private:
         texts.reserve(sections.size());
         for (const auto& s : sections) texts.push_back(s.text);
         BatchPreprocessor bp(ctx_);
-        BatchResult r = bp.run(texts, st);
+        // descriptors + the chunk texts rendered on the GPU: 1.03 bytes per input byte over the link instead of the
+        // 2.44 of every array (the preprocessed text and the token table stay on the device)
+        BatchResult r = bp.run_select(texts, st, TRP_OUT_CHUNKS | TRP_OUT_CHUNK_TEXT);
         batches_++;
         std::vector<size_t> raw(sections.size());
         bool denoising = st.denoiser && st.denoiser->enabled;
